@@ -1,0 +1,402 @@
+// BatchNorm2d (training-mode batch statistics, eval-mode running statistics) + ReLU + residual add,
+// forward and backward, NHWC.  HBM-bound elementwise / reduction kernels: 16-byte accesses per lane,
+// two-stage deterministic reductions (per-block partial rows -> fp64 finalize), no float atomics.
+// Semantics follow torch.nn.BatchNorm2d(eps=1e-5, momentum=0.1) as used by smp Unet(resnet34)
+// (SURVEY.md §2.3 K5/K6): biased variance for normalisation, unbiased for running_var.
+#include "ops.h"
+
+namespace flair {
+
+// partial [nblk][2][C] -> scale/shift (+ saved mean / invstd, running-stat update)
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                   float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  __shared__ double sh[2][32][33];
+  const int cx = threadIdx.x, ry = threadIdx.y;
+  const int c = blockIdx.x * 32 + cx;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int b = ry; b < nblk; b += 32) {
+      s1 += (double)partial[((long)b * 2 + 0) * C + c];
+      s2 += (double)partial[((long)b * 2 + 1) * C + c];
+    }
+  }
+  sh[0][ry][cx] = s1;
+  sh[1][ry][cx] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int r = 0; r < 32; ++r) { a1 += sh[0][r][cx]; a2 += sh[1][r][cx]; }
+    const double mean = a1 / count;
+    double var = a2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (mean_out) mean_out[c] = (float)mean;
+    if (invstd_out) invstd_out[c] = invstd;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+  }
+}
+
+// out = [relu]( y*scale + shift [+ res | + res*rscale + rshift] )
+template <typename T>
+__global__ void bn_act_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                              const T* __restrict__ res, const float* __restrict__ rscale,
+                              const float* __restrict__ rshift, T* __restrict__ out, long rows, int C, int relu) {
+  constexpr int CH = Elem<T>::CH;
+  const int cpr = C / CH;
+  const long total = rows * cpr;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cpr) * CH;
+    float f[CH];
+    chunk_to_f<T>(*reinterpret_cast<const uint4*>(y + idx * CH), f);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) f[e] = fmaf(f[e], scale[c + e], shift[c + e]);
+    if (res) {
+      float r[CH];
+      chunk_to_f<T>(*reinterpret_cast<const uint4*>(res + idx * CH), r);
+      if (rscale) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) r[e] = fmaf(r[e], rscale[c + e], rshift[c + e]);
+      }
+#pragma unroll
+      for (int e = 0; e < CH; ++e) f[e] += r[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
+    }
+    *reinterpret_cast<uint4*>(out + idx * CH) = f_to_chunk<T>(f);
+  }
+}
+
+// partial[blk][0][c] = sum dz ; partial[blk][1][c] = sum dz * xhat ; dz = dout * (out > 0)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                            const T* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            float* __restrict__ partial, long rows, int C,
+                                                            long rows_per_block) {
+  constexpr int CH = Elem<T>::CH;
+  __shared__ float sh[256 * 2 * CH];
+  const int cpr = C / CH;           // chunk columns (<= 128)
+  const int rl_n = 256 / cpr;       // row lanes
+  const int t = threadIdx.x;
+  const int cx = t % cpr, rl = t / cpr;
+  const int c = cx * CH;
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  float mu[CH], is[CH];
+  if (rl < rl_n) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long r = r0 + rl; r < r1; r += rl_n) {
+      const long off = r * C + c;
+      float d[CH], yy[CH];
+      chunk_to_f<T>(*reinterpret_cast<const uint4*>(dout + off), d);
+      chunk_to_f<T>(*reinterpret_cast<const uint4*>(y + off), yy);
+      if (out) {
+        float o[CH];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(out + off), o);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        s1[e] += d[e];
+        s2[e] += d[e] * ((yy[e] - mu[e]) * is[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { sh[(t * 2 + 0) * CH + e] = s1[e]; sh[(t * 2 + 1) * CH + e] = s2[e]; }
+  __syncthreads();
+  // tree over row lanes (rl_n is a power of two because C and CH are)
+  for (int stride = rl_n >> 1; stride > 0; stride >>= 1) {
+    if (rl < stride) {
+      const int o = (rl + stride) * cpr + cx;
+#pragma unroll
+      for (int e = 0; e < 2 * CH; ++e) sh[t * 2 * CH + e] += sh[o * 2 * CH + e];
+    }
+    __syncthreads();
+  }
+  if (rl == 0) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      partial[((long)blockIdx.x * 2 + 0) * C + c + e] = sh[(t * 2 + 0) * CH + e];
+      partial[((long)blockIdx.x * 2 + 1) * C + c + e] = sh[(t * 2 + 1) * CH + e];
+    }
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                       float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
+  __shared__ double sh[2][32][33];
+  const int cx = threadIdx.x, ry = threadIdx.y;
+  const int c = blockIdx.x * 32 + cx;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int b = ry; b < nblk; b += 32) {
+      s1 += (double)partial[((long)b * 2 + 0) * C + c];
+      s2 += (double)partial[((long)b * 2 + 1) * C + c];
+    }
+  }
+  sh[0][ry][cx] = s1;
+  sh[1][ry][cx] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int r = 0; r < 32; ++r) { a1 += sh[0][r][cx]; a2 += sh[1][r][cx]; }
+    if (dgamma) {
+      dgamma[c] = accumulate ? dgamma[c] + (float)a2 : (float)a2;
+      dbeta[c] = accumulate ? dbeta[c] + (float)a1 : (float)a1;
+    }
+    k1[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
+    k2[c] = (float)(a1 / count);
+    k3[c] = (float)(a2 / count);
+  }
+}
+
+// dy = k1*(dz - k2 - xhat*k3) ; optional dres (+)= dz
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ k1, const float* __restrict__ k2,
+                                    const float* __restrict__ k3, T* __restrict__ dy, T* __restrict__ dres,
+                                    int dres_accumulate, long rows, int C) {
+  constexpr int CH = Elem<T>::CH;
+  const int cpr = C / CH;
+  const long total = rows * cpr;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cpr) * CH;
+    float d[CH], yy[CH];
+    chunk_to_f<T>(*reinterpret_cast<const uint4*>(dout + idx * CH), d);
+    chunk_to_f<T>(*reinterpret_cast<const uint4*>(y + idx * CH), yy);
+    if (out) {
+      float o[CH];
+      chunk_to_f<T>(*reinterpret_cast<const uint4*>(out + idx * CH), o);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+    }
+    if (dres) {
+      float r[CH];
+      if (dres_accumulate) {
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(dres + idx * CH), r);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) r[e] += d[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) r[e] = d[e];
+      }
+      *reinterpret_cast<uint4*>(dres + idx * CH) = f_to_chunk<T>(r);
+    }
+    float g[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      const float xh = (yy[e] - mean[c + e]) * invstd[c + e];
+      g[e] = k1[c + e] * (d[e] - k2[c + e] - xh * k3[c + e]);
+    }
+    *reinterpret_cast<uint4*>(dy + idx * CH) = f_to_chunk<T>(g);
+  }
+}
+
+// column sums of x[rows][ld] (first C columns) -> out[C]; two-stage, deterministic (head bias gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const T* __restrict__ x, long rows, int ld,
+                                                            float* __restrict__ partial, long rows_per_block) {
+  constexpr int CH = Elem<T>::CH;
+  __shared__ float sh[256 * CH];
+  const int cpr = ld / CH, rl_n = 256 / cpr, t = threadIdx.x;
+  const int cx = t % cpr, rl = t / cpr;
+  float s1[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) s1[e] = 0.f;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (long r = r0 + rl; r < r1; r += rl_n) {
+    float d[CH];
+    chunk_to_f<T>(*reinterpret_cast<const uint4*>(x + r * ld + cx * CH), d);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) s1[e] += d[e];
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) sh[t * CH + e] = s1[e];
+  __syncthreads();
+  for (int stride = rl_n >> 1; stride > 0; stride >>= 1) {
+    if (rl < stride) {
+      const int o = (rl + stride) * cpr + cx;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) sh[t * CH + e] += sh[o * CH + e];
+    }
+    __syncthreads();
+  }
+  if (rl == 0) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) partial[(long)blockIdx.x * ld + cx * CH + e] = sh[t * CH + e];
+  }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int ld, int C, float* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c < C) {
+    double a = 0.0;
+    for (int b = 0; b < nblk; ++b) a += (double)partial[(long)b * ld + c];
+    out[c] = (float)a;
+  }
+}
+
+static inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int bn_finalize(const float* partial, int nblk, int C, long count, const float* gamma, const float* beta,
+                float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                float* mean_out, float* invstd_out, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 32), 0, s, partial, nblk, C, (double)count, gamma,
+                     beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                   float* scale, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, C, gamma, beta, rm, rv, eps, scale, shift);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
+           const float* rshift, void* out, long rows, int C, int relu, hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (C % ch) return -2;
+  const long total = rows * (C / ch);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)y, scale, shift,
+                       (const float*)res, rscale, rshift, (float*)out, rows, C, relu);
+  else
+    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)y, scale, shift,
+                       (const bf16_t*)res, rscale, rshift, (bf16_t*)out, rows, C, relu);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int bn_bwd_blocks(long rows) {
+  long b = (rows + 255) / 256;  // >= 256 rows per block
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__global__ void partial_rows_sum_kernel(const float* __restrict__ partial, int nblk, int ld, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < ld) {
+    double a = 0.0;
+    for (int b = 0; b < nblk; ++b) a += (double)partial[(long)b * ld + c];
+    out[c] = (float)a;
+  }
+}
+
+int partial_rows_sum(const float* partial, int nblk, int ld, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(partial_rows_sum_kernel, dim3(cdiv(ld, 256)), dim3(256), 0, s, partial, nblk, ld, out);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+// per-block partial (sum y, sum y^2) of a standalone tensor: [bn_bwd_blocks(rows)][2][C]
+// zeros_ones: scratch of 2*C floats (filled here with mean = 0, invstd = 1)
+int bn_stats_partial(int dtype, const void* y, long rows, int C, float* partial, float* zeros_ones, hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (C % ch || C / ch > 128) return -2;
+  int rc = fill_f32(zeros_ones, C, 0.f, s);
+  if (rc) return rc;
+  rc = fill_f32(zeros_ones + C, C, 1.f, s);
+  if (rc) return rc;
+  const int nblk = bn_bwd_blocks(rows);
+  const long rpb = (rows + nblk - 1) / nblk;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, s, (const float*)y, (const float*)nullptr,
+                       (const float*)y, zeros_ones, zeros_ones + C, partial, rows, C, rpb);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)y,
+                       (const bf16_t*)nullptr, (const bf16_t*)y, zeros_ones, zeros_ones + C, partial, rows, C, rpb);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int colsum(int dtype, const void* x, long rows, int ld, int C, float* partial, float* out, hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (ld % ch || ld / ch > 256 || C > 64) return -2;
+  const int nblk = bn_bwd_blocks(rows);
+  const long rpb = (rows + nblk - 1) / nblk;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(colsum_reduce_kernel<float>, dim3(nblk), dim3(256), 0, s, (const float*)x, rows, ld, partial, rpb);
+  else
+    hipLaunchKernelGGL(colsum_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, rows, ld, partial, rpb);
+  FLAIR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nblk, ld, C, out);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int bn_backward(int dtype, const void* dout, const void* out, const void* y, const float* mean, const float* invstd,
+                const float* gamma, long rows, int C, float* partial, float* coef /*3*C*/, float* dgamma, float* dbeta,
+                int accumulate_param, void* dy, void* dres, int dres_accumulate, hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (C % ch || C / ch > 128) return -2;
+  const int nblk = bn_bwd_blocks(rows);
+  const long rpb = (rows + nblk - 1) / nblk;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, s, (const float*)dout, (const float*)out,
+                       (const float*)y, mean, invstd, partial, rows, C, rpb);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)dout,
+                       (const bf16_t*)out, (const bf16_t*)y, mean, invstd, partial, rows, C, rpb);
+  FLAIR_CHECK_LAUNCH();
+  float *k1 = coef, *k2 = coef + C, *k3 = coef + 2 * C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 32), 0, s, partial, nblk, C, (double)rows, gamma,
+                     invstd, dgamma, dbeta, accumulate_param, k1, k2, k3);
+  FLAIR_CHECK_LAUNCH();
+  const long total = rows * (C / ch);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)dout,
+                       (const float*)out, (const float*)y, mean, invstd, k1, k2, k3, (float*)dy, (float*)dres,
+                       dres_accumulate, rows, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)dout,
+                       (const bf16_t*)out, (const bf16_t*)y, mean, invstd, k1, k2, k3, (bf16_t*)dy, (bf16_t*)dres,
+                       dres_accumulate, rows, C);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace flair

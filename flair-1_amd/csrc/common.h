@@ -1,0 +1,114 @@
+// Shared device/host helpers for the FLAIR segmentation hot path on gfx950 (MI355X).
+// All activations are NHWC in HBM; T is float (parity mode) or bf16 (throughput mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace flair {
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+__host__ __device__ inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int CH = 4;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ float to_f(float v) { return v; }
+  __device__ static __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int CH = 8;
+  __device__ static __forceinline__ float to_f(bf16_t v) { return bf16_to_f32(v); }
+  __device__ static __forceinline__ bf16_t from_f(float v) { return f32_to_bf16(v); }
+};
+
+// unpack / pack one 16-byte chunk to floats
+template <typename T> __device__ __forceinline__ void chunk_to_f(const uint4& c, float* f);
+template <> __device__ __forceinline__ void chunk_to_f<float>(const uint4& c, float* f) {
+  f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y); f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+}
+template <> __device__ __forceinline__ void chunk_to_f<bf16_t>(const uint4& c, float* f) {
+  f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
+  f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
+  f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
+  f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 f_to_chunk(const float* f);
+template <> __device__ __forceinline__ uint4 f_to_chunk<float>(const float* f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 f_to_chunk<bf16_t>(const float* f) {
+  uint4 r;
+  r.x = (unsigned)f32_to_bf16(f[0]) | ((unsigned)f32_to_bf16(f[1]) << 16);
+  r.y = (unsigned)f32_to_bf16(f[2]) | ((unsigned)f32_to_bf16(f[3]) << 16);
+  r.z = (unsigned)f32_to_bf16(f[4]) | ((unsigned)f32_to_bf16(f[5]) << 16);
+  r.w = (unsigned)f32_to_bf16(f[6]) | ((unsigned)f32_to_bf16(f[7]) << 16);
+  return r;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+#define FLAIR_CHECK_LAUNCH()                                   \
+  do {                                                         \
+    hipError_t e__ = hipGetLastError();                        \
+    if (e__ != hipSuccess) return (int)e__;                    \
+  } while (0)
+
+// ----------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (forward and data-gradient share one gather-form kernel).
+struct ConvArgs {
+  const void* src0;  // NHWC T, C0 channels (at half resolution when up0)
+  const void* src1;  // NHWC T, C1 channels (skip), may be null
+  int C0, C1;        // Cin = C0 + C1 (each a multiple of the 16-byte chunk)
+  int up0;           // nearest x2 upsample of src0 fused into the gather
+  int N, Hin, Win;   // logical input extent (after the upsample)
+  int Hout, Wout;
+  int R, S;
+  int out_mul, pad, in_div;  // num = o*out_mul - pad + r ; tap valid iff num % in_div == 0 ; i = num / in_div
+  int Cout;          // real output channels
+  int Kg;            // R*S*Cin
+  int Kpad;          // row length of the packed weight (multiple of the K step)
+  const void* w;     // packed [Cout_pad][Kpad] T, kk = (r*S+s)*Cin + c
+  const float* bias; // optional [Cout]
+  void* out;         // NHWC T, row stride out_ld elements (null when only out_nchw is wanted)
+  int out_ld;
+  float* out_nchw;   // optional fp32 NCHW [N][Cout][Hout][Wout]
+  float* stats;      // optional per-row-block partial sums [gridDim.x][2][Cout] (sum, sum of squares)
+  int accumulate;    // out += result
+  // optional fused input transform on src0/src1: x' = relu(x*scale[c] + shift[c]) (per concatenated channel)
+  const float* in_scale;
+  const float* in_shift;
+};
+
+int launch_conv(int dtype, const ConvArgs& a, hipStream_t s);
+int conv_grid_rows(int dtype, const ConvArgs& a);  // number of row blocks (= partial-stat rows)
+
+// Weight gradient: dW[k][(r,s),c] = sum_p dY[p][k] * im2col(X)[p][(r,s),c]; split over pixels.
+struct WgradArgs {
+  const void* x0; const void* x1; int C0, C1, up0;  // same gather as the forward conv
+  int N, Hin, Win, Hout, Wout, R, S, stride, pad;
+  const void* dy; int dy_ld; int Cout;               // NHWC T [M][dy_ld], first Cout channels used
+  float* partial;                                    // [splits][Cout_pad][Kpad] fp32 workspace
+  float* dw;                                         // OIHW fp32 [Cout][Cin_real][R][S]
+  int Cin_real;                                      // channels of dw (<= C0+C1, rest is padding)
+  int accumulate;
+};
+int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);
+size_t wgrad_workspace_bytes(int dtype, const WgradArgs& a);
+
+}  // namespace flair

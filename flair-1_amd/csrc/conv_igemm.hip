@@ -1,0 +1,314 @@
+// Implicit-GEMM convolution for gfx950: D[pixel][cout] = sum_k im2col(X)[pixel][k] * W[cout][k].
+//
+// One gather-form kernel serves
+//   * every forward conv of smp Unet(resnet34) (7x7 s2, 3x3 s1/s2, 1x1 s2),
+//   * the decoder's nearest-x2 upsample + skip concat, fused into the gather (two sources),
+//   * the data gradient (flipped/transposed packed weights, in_div = forward stride).
+// K is walked in 128-byte steps (64 bf16 / 32 f32) through a double-buffered, XOR-swizzled LDS
+// image with 128-byte rows (conflict-free ds_read_b128, cdna_hip_programming.md §5.5 T2);
+// MFMA 16x16x32 bf16 (throughput) or 16x16x4 f32 (parity: exact fp32 FMA chain).
+// Epilogue: accumulators -> LDS -> 16-byte coalesced NHWC stores (or fp32 NCHW for the head),
+// plus per-row-block partial BatchNorm sums (deterministic: no atomics).
+#include "common.h"
+
+namespace flair {
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&a),
+                                                *reinterpret_cast<const bf16x8_t*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+struct ConvCfg {
+  static constexpr int CH = Elem<T>::CH;
+  static constexpr int BKE = 8 * CH;
+  static constexpr int STAGE = (BM + BN) * 128;
+  static constexpr int CLD = BN * (int)sizeof(T) + 16;
+  static constexpr int CT = BM * CLD;
+  static constexpr int MAIN = (2 * STAGE > CT) ? 2 * STAGE : CT;
+  static constexpr int STATS = WAVES_M * BN * 2 * 4;
+  static constexpr int SMEM = MAIN + STATS;
+};
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  using Cfg = ConvCfg<T, BM, BN, WAVES_M, WAVES_N>;
+  constexpr int CH = Cfg::CH, BKE = Cfg::BKE;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int AROWS = BM / 32;
+  constexpr int BROWS = (BN + 31) / 32;
+  static_assert(WAVES_M * WAVES_N == 4, "256 threads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const long M = (long)a.N * a.Hout * a.Wout;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int Cin = a.C0 + a.C1;
+  const int cc = t & 7, rb = t >> 3;
+  const T* __restrict__ src0 = (const T*)a.src0;
+  const T* __restrict__ src1 = (const T*)a.src1;
+  const T* __restrict__ wp = (const T*)a.w;
+
+  int ih0[AROWS], iw0[AROWS], nb[AROWS];
+  {
+    const int HW = a.Hout * a.Wout;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      long m = m0 + rb + 32 * i;
+      if (m < M) {
+        int n = (int)(m / HW);
+        int rem = (int)(m - (long)n * HW);
+        int ho = rem / a.Wout, wo = rem - ho * a.Wout;
+        ih0[i] = ho * a.out_mul - a.pad;
+        iw0[i] = wo * a.out_mul - a.pad;
+        nb[i] = n;
+      } else {
+        ih0[i] = -(1 << 28); iw0[i] = -(1 << 28); nb[i] = 0;
+      }
+    }
+  }
+  // K decode for this thread's chunk column
+  int kc, kr, ks;
+  {
+    int kk = cc * CH;
+    int tap = kk / Cin;
+    kc = kk - tap * Cin;
+    kr = tap / a.S;
+    ks = tap - kr * a.S;
+  }
+  const int Hs0 = a.up0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.up0 ? (a.Win >> 1) : a.Win;
+  const int nsteps = a.Kpad / BKE;
+
+  uint4 areg[AROWS], breg[BROWS];
+  auto load_regs = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      int hn = ih0[i] + kr, wq = iw0[i] + ks;
+      bool ok = kr < a.R;
+      if (a.in_div == 2) {
+        ok = ok && (((hn | wq) & 1) == 0);
+        hn >>= 1; wq >>= 1;
+      }
+      ok = ok && ((unsigned)hn < (unsigned)a.Hin) && ((unsigned)wq < (unsigned)a.Win);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        const T* p;
+        if (kc < a.C0) {
+          int hs = a.up0 ? (hn >> 1) : hn, ws = a.up0 ? (wq >> 1) : wq;
+          p = src0 + (((long)nb[i] * Hs0 + hs) * Ws0 + ws) * a.C0 + kc;
+        } else {
+          p = src1 + (((long)nb[i] * a.Hin + hn) * a.Win + wq) * a.C1 + (kc - a.C0);
+        }
+        v = *reinterpret_cast<const uint4*>(p);
+        if (a.in_scale) {
+          float f[CH];
+          chunk_to_f<T>(v, f);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) f[e] = fmaxf(fmaf(f[e], a.in_scale[kc + e], a.in_shift[kc + e]), 0.f);
+          v = f_to_chunk<T>(f);
+        }
+      }
+      areg[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      int row = rb + 32 * j;
+      if (row < BN)
+        breg[j] = *reinterpret_cast<const uint4*>(wp + (long)(n0 + row) * a.Kpad + (long)step * BKE + cc * CH);
+    }
+    // advance the K decode by one step
+    kc += BKE;
+    while (kc >= Cin) {
+      kc -= Cin;
+      if (++ks == a.S) { ks = 0; ++kr; }
+    }
+  };
+  auto write_lds = [&](int stage) {
+    unsigned char* sA = smem + stage * Cfg::STAGE;
+    unsigned char* sB = sA + BM * 128;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) *reinterpret_cast<uint4*>(sA + lds_off(rb + 32 * i, cc)) = areg[i];
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      int row = rb + 32 * j;
+      if (row < BN) *reinterpret_cast<uint4*>(sB + lds_off(row, cc)) = breg[j];
+    }
+  };
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  load_regs(0);
+  write_lds(0);
+  __syncthreads();
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    const bool more = step + 1 < nsteps;
+    if (more) load_regs(step + 1);
+    const unsigned char* sA = smem + cur * Cfg::STAGE;
+    const unsigned char* sB = sA + BM * 128;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint4 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const uint4*>(sA + lds_off(wm * WM + i * 16 + lr, lq + 4 * h));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *reinterpret_cast<const uint4*>(sB + lds_off(wn * WN + j * 16 + lr, lq + 4 * h));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+    }
+    if (more) write_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  unsigned char* ct = smem;  // C tile [BM][CLD bytes]; all stage reads are behind the barrier above
+  float* st = reinterpret_cast<float*>(smem + Cfg::MAIN);
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * WN + j * 16 + lr;
+    const float bias = (a.bias && (n0 + col) < a.Cout) ? a.bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * WM + i * 16 + lq * 4 + r;
+        T v = Elem<T>::from_f(acc[i][j][r] + bias);
+        float vf = Elem<T>::to_f(v);
+        s1[j] += vf;
+        s2[j] += vf * vf;
+        *reinterpret_cast<T*>(ct + row * Cfg::CLD + col * (int)sizeof(T)) = v;
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 16); s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 16); s2[j] += __shfl_xor(s2[j], 32);
+      if (lq == 0) {
+        st[(wm * BN + wn * WN + j * 16 + lr) * 2 + 0] = s1[j];
+        st[(wm * BN + wn * WN + j * 16 + lr) * 2 + 1] = s2[j];
+      }
+    }
+  }
+  __syncthreads();
+  if (a.stats && t < BN && (n0 + t) < a.Cout) {
+    float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES_M; ++w) { x1 += st[(w * BN + t) * 2]; x2 += st[(w * BN + t) * 2 + 1]; }
+    a.stats[((long)blockIdx.x * 2 + 0) * a.Cout + n0 + t] = x1;
+    a.stats[((long)blockIdx.x * 2 + 1) * a.Cout + n0 + t] = x2;
+  }
+  if (a.out) {
+    constexpr int CPR = BN / CH;
+    T* __restrict__ out = (T*)a.out;
+    for (int idx = t; idx < BM * CPR; idx += 256) {
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const long m = m0 + row;
+      const int n = n0 + ch * CH;
+      if (m < M && n < a.Cout) {
+        uint4 v = *reinterpret_cast<const uint4*>(ct + row * Cfg::CLD + ch * 16);
+        T* dst = out + m * a.out_ld + n;
+        if (a.accumulate) {
+          uint4 o = *reinterpret_cast<const uint4*>(dst);
+          float fa[CH], fb[CH];
+          chunk_to_f<T>(v, fa);
+          chunk_to_f<T>(o, fb);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) fa[e] += fb[e];
+          v = f_to_chunk<T>(fa);
+        }
+        *reinterpret_cast<uint4*>(dst) = v;
+      }
+    }
+  }
+  if (a.out_nchw) {
+    const int HW = a.Hout * a.Wout;
+    for (int idx = t; idx < BM * BN; idx += 256) {
+      const int nl = idx / BM, ml = idx - nl * BM;
+      const long m = m0 + ml;
+      const int n = n0 + nl;
+      if (m < M && n < a.Cout) {
+        const long img = m / HW, pix = m - img * HW;
+        a.out_nchw[(img * a.Cout + n) * HW + pix] =
+            Elem<T>::to_f(*reinterpret_cast<const T*>(ct + ml * Cfg::CLD + nl * (int)sizeof(T)));
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_cfg(const ConvArgs& a, hipStream_t s) {
+  using Cfg = ConvCfg<T, BM, BN, WAVES_M, WAVES_N>;
+  const long M = (long)a.N * a.Hout * a.Wout;
+  dim3 grid(cdiv(M, BM), cdiv(a.Cout, BN));
+  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::SMEM, s, a);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+static inline int pick_bn(int cout) { return cout >= 128 ? 128 : cout >= 64 ? 64 : cout >= 32 ? 32 : 16; }
+static inline int pick_bm(int cout) { return cout >= 64 ? 128 : 256; }
+
+int conv_grid_rows(int dtype, const ConvArgs& a) {
+  (void)dtype;
+  return cdiv((long)a.N * a.Hout * a.Wout, pick_bm(a.Cout));
+}
+
+int conv_weight_rows_pad(int cout) { return (int)round_up(cout, pick_bn(cout)); }
+
+template <typename T>
+static int launch_t(const ConvArgs& a, hipStream_t s) {
+  constexpr int CH = Elem<T>::CH;
+  if ((a.C0 % CH) || (a.C1 % CH) || (a.Kpad % (8 * CH))) return -2;
+  if (a.out && (a.Cout % CH)) return -3;
+  if (a.up0 && ((a.Hin | a.Win) & 1)) return -4;
+  if (a.in_div != 1 && a.in_div != 2) return -5;
+  switch (pick_bn(a.Cout)) {
+    case 128: return launch_cfg<T, 128, 128, 2, 2>(a, s);
+    case 64: return launch_cfg<T, 128, 64, 4, 1>(a, s);
+    case 32: return launch_cfg<T, 256, 32, 4, 1>(a, s);
+    default: return launch_cfg<T, 256, 16, 4, 1>(a, s);
+  }
+}
+
+int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
+  return dtype == DT_F32 ? launch_t<float>(a, s) : launch_t<bf16_t>(a, s);
+}
+
+}  // namespace flair

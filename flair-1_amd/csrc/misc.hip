@@ -1,0 +1,356 @@
+// HBM-bound helpers of the U-Net hot path (NHWC, 16 bytes per lane): max-pool 3x3/s2 fwd+bwd,
+// backward of the fused nearest-x2-upsample + concat, NCHW fp32 <-> NHWC T boundary converters,
+// weight packing (PyTorch OIHW fp32 master -> [Cout][(r,s),c] T, optionally flipped/transposed for
+// the data gradient), plain SGD (src/flair/tasks_utils.py:95) and small utilities.
+#include "ops.h"
+
+namespace flair {
+
+static inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------- maxpool 3x3 stride 2 pad 1
+// First maximum in (kh, kw) scan order wins, like torch.nn.MaxPool2d on CPU; idx keeps the tap.
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, unsigned char* __restrict__ idx,
+                                   int N, int H, int W, int C) {
+  constexpr int CH = Elem<T>::CH;
+  const int Ho = H / 2, Wo = W / 2, cpr = C / CH;
+  const long total = (long)N * Ho * Wo * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cx = (int)(i % cpr);
+    long p = i / cpr;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float best[CH];
+    unsigned char bi[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    bool first = true;
+    for (int r = 0; r < 3; ++r) {
+      const int h = 2 * ho - 1 + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int q = 0; q < 3; ++q) {
+        const int w = 2 * wo - 1 + q;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float f[CH];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(in + (((long)n * H + h) * W + w) * C + cx * CH), f);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          if (first || f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; bi[e] = (unsigned char)(r * 3 + q); }
+        }
+        first = false;
+      }
+    }
+    *reinterpret_cast<uint4*>(out + i * CH) = f_to_chunk<T>(best);
+    if (idx) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) idx[i * CH + e] = bi[e];
+    }
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ idx,
+                                   T* __restrict__ din, int accumulate, int N, int H, int W, int C) {
+  constexpr int CH = Elem<T>::CH;
+  const int Ho = H / 2, Wo = W / 2, cpr = C / CH;
+  const long total = (long)N * H * W * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cx = (int)(i % cpr);
+    long p = i / cpr;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    float g[CH];
+    if (accumulate) chunk_to_f<T>(*reinterpret_cast<const uint4*>(din + i * CH), g);
+    else {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) g[e] = 0.f;
+    }
+    for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
+      if (ho >= Ho) continue;
+      const int r = h - (2 * ho - 1);
+      for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
+        if (wo >= Wo) continue;
+        const int q = w - (2 * wo - 1);
+        const unsigned char tap = (unsigned char)(r * 3 + q);
+        const long o = ((((long)n * Ho + ho) * Wo + wo) * cpr + cx) * CH;
+        float d[CH];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(dout + o), d);
+#pragma unroll
+        for (int e = 0; e < CH; ++e)
+          if (idx[o + e] == tap) g[e] += d[e];
+      }
+    }
+    *reinterpret_cast<uint4*>(din + i * CH) = f_to_chunk<T>(g);
+  }
+}
+
+// ---------------------------------------------------------------- backward of cat([up2(x0), skip])
+template <typename T>
+__global__ void upcat_bwd_kernel(const T* __restrict__ dcat, T* __restrict__ dx0, int dx0_acc, T* __restrict__ dskip,
+                                 int dskip_acc, int N, int H, int W, int C0, int C1) {
+  constexpr int CH = Elem<T>::CH;
+  const int Ct = C0 + C1;
+  const int c0r = C0 / CH, c1r = C1 / CH;
+  const int Hh = H / 2, Wh = W / 2;
+  const long n0 = (long)N * Hh * Wh * c0r;
+  const long n1 = (long)N * H * W * c1r;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += (long)gridDim.x * blockDim.x) {
+    if (i < n0) {
+      const int cx = (int)(i % c0r);
+      long p = i / c0r;
+      const int w = (int)(p % Wh); p /= Wh;
+      const int h = (int)(p % Hh);
+      const int n = (int)(p / Hh);
+      float g[CH];
+      if (dx0_acc) chunk_to_f<T>(*reinterpret_cast<const uint4*>(dx0 + i * CH), g);
+      else {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) g[e] = 0.f;
+      }
+#pragma unroll
+      for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+          float d[CH];
+          chunk_to_f<T>(*reinterpret_cast<const uint4*>(dcat + (((long)n * H + 2 * h + dh) * W + 2 * w + dw) * Ct + cx * CH), d);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) g[e] += d[e];
+        }
+      *reinterpret_cast<uint4*>(dx0 + i * CH) = f_to_chunk<T>(g);
+    } else {
+      const long j = i - n0;
+      const int cx = (int)(j % c1r);
+      const long p = j / c1r;
+      uint4 v = *reinterpret_cast<const uint4*>(dcat + p * Ct + C0 + cx * CH);
+      if (dskip_acc) {
+        float a[CH], b[CH];
+        chunk_to_f<T>(v, a);
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(dskip + j * CH), b);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) a[e] += b[e];
+        v = f_to_chunk<T>(a);
+      }
+      *reinterpret_cast<uint4*>(dskip + j * CH) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- layout converters at the NCHW fp32 boundary
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int C, long HW, int Cp) {
+  constexpr int CH = Elem<T>::CH;
+  const long total = (long)N * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / HW, pix = i - n * HW;
+    const float* src = in + n * C * HW + pix;
+    for (int c0 = 0; c0 < Cp; c0 += CH) {
+      float f[CH];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) f[e] = (c0 + e) < C ? src[(long)(c0 + e) * HW] : 0.f;
+      *reinterpret_cast<uint4*>(out + i * Cp + c0) = f_to_chunk<T>(f);
+    }
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int N, int C, long HW, int Cp,
+                                    int accumulate) {
+  constexpr int CH = Elem<T>::CH;
+  const long total = (long)N * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / HW, pix = i - n * HW;
+    float* dst = out + n * C * HW + pix;
+    for (int c0 = 0; c0 < Cp; c0 += CH) {
+      float f[CH];
+      chunk_to_f<T>(*reinterpret_cast<const uint4*>(in + i * Cp + c0), f);
+#pragma unroll
+      for (int e = 0; e < CH; ++e)
+        if (c0 + e < C) {
+          float* d = dst + (long)(c0 + e) * HW;
+          *d = accumulate ? (*d + f[e]) : f[e];
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight packing
+// forward:  dst[k][(r*S+s)*Cin_p + c] = w[k][c][r][s]
+// dgrad  :  dst[c][(r*S+s)*Cin_p + k] = w[k][c][R-1-r][S-1-s]   (rows = forward Cin, Cin_p = padded forward Cout)
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int R, int S,
+                                   int Cin_p, int rows_pad, int Kpad, int tf) {
+  const long total = (long)rows_pad * Kpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / Kpad), kk = (int)(i - (long)row * Kpad);
+    const int tap = kk / Cin_p, c = kk - tap * Cin_p;
+    float v = 0.f;
+    if (tap < R * S) {
+      const int r = tap / S, q = tap - r * S;
+      if (!tf) {
+        if (row < Cout && c < Cin) v = w[(((long)row * Cin + c) * R + r) * S + q];
+      } else {
+        if (row < Cin && c < Cout) v = w[(((long)c * Cin + row) * R + (R - 1 - r)) * S + (S - 1 - q)];
+      }
+    }
+    dst[i] = Elem<T>::from_f(v);
+  }
+}
+
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, long n, float lr) {
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<float4*>(p)[i];
+    const float4 b = reinterpret_cast<const float4*>(g)[i];
+    a.x -= lr * b.x; a.y -= lr * b.y; a.z -= lr * b.z; a.w -= lr * b.w;
+    reinterpret_cast<float4*>(p)[i] = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = n4 * 4 + threadIdx.x;
+    p[i] -= lr * g[i];
+  }
+}
+
+// x[n][c][h][w] += v[n][h]   (metadata fusion layout quirk, src/flair/model.py:59-60: the 16-d
+// encoding varies along H only, constant over channels and W)
+__global__ void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v, int N, int C, int H, int W) {
+  const long total = (long)N * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int h = (int)((i / W) % H);
+    const int n = (int)(i / ((long)C * H * W));
+    x[i] += v[n * H + h];
+  }
+}
+
+template <typename T>
+__global__ void ew_add_kernel(T* __restrict__ dst, const T* __restrict__ src, long nchunks) {
+  constexpr int CH = Elem<T>::CH;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    float a[CH], b[CH];
+    chunk_to_f<T>(*reinterpret_cast<const uint4*>(dst + i * CH), a);
+    chunk_to_f<T>(*reinterpret_cast<const uint4*>(src + i * CH), b);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) a[e] += b[e];
+    *reinterpret_cast<uint4*>(dst + i * CH) = f_to_chunk<T>(a);
+  }
+}
+
+int maxpool3x3s2_fwd(int dtype, const void* in, void* out, unsigned char* idx, int N, int H, int W, int C, hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (C % ch || (H & 1) || (W & 1)) return -2;
+  const long total = (long)N * (H / 2) * (W / 2) * (C / ch);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, (float*)out, idx, N, H, W, C);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, idx, N, H, W, C);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, void* din, int accumulate, int N, int H,
+                     int W, int C, hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (C % ch || (H & 1) || (W & 1)) return -2;
+  const long total = (long)N * H * W * (C / ch);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)dout, idx, (float*)din, accumulate, N, H, W, C);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)dout, idx, (bf16_t*)din, accumulate, N, H, W, C);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int upcat_bwd(int dtype, const void* dcat, void* dx0, int dx0_accumulate, void* dskip, int dskip_accumulate, int N,
+              int H, int W, int C0, int C1, hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (C0 % ch || C1 % ch || (H & 1) || (W & 1)) return -2;
+  const long total = (long)N * (H / 2) * (W / 2) * (C0 / ch) + (long)N * H * W * (C1 / ch);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(upcat_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)dcat, (float*)dx0, dx0_accumulate, (float*)dskip, dskip_accumulate, N, H, W, C0, C1);
+  else
+    hipLaunchKernelGGL(upcat_bwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)dcat, (bf16_t*)dx0, dx0_accumulate, (bf16_t*)dskip, dskip_accumulate, N, H, W, C0, C1);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int nchw_f32_to_nhwc(int dtype, const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (Cp % ch || Cp < C) return -2;
+  const long total = (long)N * H * W;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, in, (float*)out, N, C, (long)H * W, Cp);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, in, (bf16_t*)out, N, C, (long)H * W, Cp);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int nhwc_to_nchw_f32(int dtype, const void* in, float* out, int N, int C, int H, int W, int Cp, float* accumulate_into,
+                     hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (Cp % ch || Cp < C) return -2;
+  const long total = (long)N * H * W;
+  float* dst = accumulate_into ? accumulate_into : out;
+  const int acc = accumulate_into ? 1 : 0;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, dst, N, C, (long)H * W, Cp, acc);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)in, dst, N, C, (long)H * W, Cp, acc);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int pack_weight(int dtype, const float* w_oihw, void* dst, int Cout, int Cin, int R, int S, int Cin_p, int rows_pad,
+                int Kpad, int transpose_flip, hipStream_t s) {
+  const long total = (long)rows_pad * Kpad;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, w_oihw, (float*)dst, Cout, Cin, R, S, Cin_p, rows_pad, Kpad, transpose_flip);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, w_oihw, (bf16_t*)dst, Cout, Cin, R, S, Cin_p, rows_pad, Kpad, transpose_flip);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int sgd_step(float* params, const float* grads, long n, float lr, hipStream_t s) {
+  if (((uintptr_t)params | (uintptr_t)grads) & 15) return -2;
+  hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, s, params, grads, n, lr);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int add_rowvec_nchw(float* x, const float* v, int N, int C, int H, int W, hipStream_t s) {
+  hipLaunchKernelGGL(add_rowvec_kernel, dim3(ew_blocks((long)N * C * H * W)), dim3(256), 0, s, x, v, N, C, H, W);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int ew_add(int dtype, void* dst, const void* src, long n, hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (n % ch) return -2;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(ew_add_kernel<float>, dim3(ew_blocks(n / ch)), dim3(256), 0, s, (float*)dst, (const float*)src, n / ch);
+  else
+    hipLaunchKernelGGL(ew_add_kernel<bf16_t>, dim3(ew_blocks(n / ch)), dim3(256), 0, s, (bf16_t*)dst, (const bf16_t*)src, n / ch);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void fill_f32_kernel(float* p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+int fill_f32(float* p, long n, float v, hipStream_t s) {
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, p, n, v);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int fill_zero(void* p, size_t bytes, hipStream_t s) { return (int)hipMemsetAsync(p, 0, bytes, s); }
+
+}  // namespace flair

@@ -1,0 +1,66 @@
+// Host-callable launchers of the elementwise / reduction kernels (bn.hip, misc.hip, ce_head.hip).
+#pragma once
+#include "common.h"
+
+namespace flair {
+
+// ---- bn.hip
+int bn_finalize(const float* partial, int nblk, int C, long count, const float* gamma, const float* beta,
+                float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                float* mean_out, float* invstd_out, hipStream_t s);
+int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                   float* scale, float* shift, hipStream_t s);
+int bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
+           const float* rshift, void* out, long rows, int C, int relu, hipStream_t s);
+int bn_bwd_blocks(long rows);
+int bn_backward(int dtype, const void* dout, const void* out, const void* y, const float* mean, const float* invstd,
+                const float* gamma, long rows, int C, float* partial, float* coef, float* dgamma, float* dbeta,
+                int accumulate_param, void* dy, void* dres, int dres_accumulate, hipStream_t s);
+
+int partial_rows_sum(const float* partial, int nblk, int ld, float* out, hipStream_t s);
+int bn_stats_partial(int dtype, const void* y, long rows, int C, float* partial, float* zeros_ones, hipStream_t s);
+int colsum(int dtype, const void* x, long rows, int ld, int C, float* partial, float* out, hipStream_t s);
+
+// ---- misc.hip
+int maxpool3x3s2_fwd(int dtype, const void* in, void* out, unsigned char* idx, int N, int H, int W, int C, hipStream_t s);
+int maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, void* din, int accumulate, int N, int H,
+                     int W, int C, hipStream_t s);
+int upcat_bwd(int dtype, const void* dcat, void* dx0, int dx0_accumulate, void* dskip, int dskip_accumulate, int N,
+              int H, int W, int C0, int C1, hipStream_t s);
+int nchw_f32_to_nhwc(int dtype, const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s);
+int nhwc_to_nchw_f32(int dtype, const void* in, float* out, int N, int C, int H, int W, int Cp, float* accumulate_into,
+                     hipStream_t s);
+int pack_weight(int dtype, const float* w_oihw, void* dst, int Cout, int Cin, int R, int S, int Cin_p, int rows_pad,
+                int Kpad, int transpose_flip, hipStream_t s);
+int sgd_step(float* params, const float* grads, long n, float lr, hipStream_t s);
+int add_rowvec_nchw(float* x, const float* v, int N, int C, int H, int W, hipStream_t s);
+int ew_add(int dtype, void* dst, const void* src, long n, hipStream_t s);
+int fill_zero(void* p, size_t bytes, hipStream_t s);
+int fill_f32(float* p, long n, float v, hipStream_t s);
+
+// ---- ce_head.hip
+struct CeArgs {
+  const float* logits;        // NCHW fp32 [B][C][H][W]
+  const void* labels;         // label map, dtype per label_kind
+  int label_kind;             // 0: uint8 [B][H][W]; 1: int32; 2: int64; 3: fp32 one-hot NCHW [B][C][H][W]
+  const float* weight;        // optional class weights [C]
+  int B, C, H, W;
+  float* loss;                // out: scalar mean loss
+  float* dlogits_nchw;        // optional out: fp32 NCHW gradient of the mean loss
+  void* dlogits_nhwc;         // optional out: NHWC T gradient, row stride ld (>= C), padded columns zeroed
+  int dlogits_dtype, dlogits_ld;
+  unsigned char* preds_u8;    // optional out [B][H][W]
+  long long* preds_i64;       // optional out [B][H][W]
+  int* targets_i32;           // optional out [B][H][W]
+  long long* confmat;         // optional in/out [C][C] += bincount(target*C + pred)
+  float* workspace;           // >= ce_workspace_floats() floats
+};
+size_t ce_workspace_floats(int B, int H, int W);
+int ce_head(const CeArgs& a, hipStream_t s);
+int softmax_argmax(const float* logits, int B, int C, int H, int W, unsigned char* preds_u8, long long* preds_i64,
+                   float* maxprob, hipStream_t s);
+int confmat_update(const void* target, int target_kind, const void* pred, int pred_kind, long n, int C,
+                   long long* confmat, hipStream_t s);
+int jaccard_from_confmat(const long long* confmat, int C, float* per_class, float* weighted, float* macro, hipStream_t s);
+
+}  // namespace flair

@@ -1,0 +1,145 @@
+// Native executor for the smp-0.3.3 Unet(resnet34) graph the reference instantiates at
+// /root/reference/src/flair/model.py:37-41 and runs at model.py:57-64.
+// Owns the layer table, the flat parameter layout, the workspace arena and
+// launches every kernel of forward / backward back-to-back on the caller's HIP stream.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "ops.h"
+
+namespace flair {
+
+struct Act {
+  void* p = nullptr;
+  int N = 0, H = 0, W = 0, C = 0;  // C = stored (padded) channel count
+  long rows() const { return (long)N * H * W; }
+  long elems() const { return rows() * C; }
+};
+
+struct ConvDesc {
+  std::string name;
+  int Cin, Cout, R, S, stride, pad;
+  int Cin_p, Cout_p;      // stored channel counts of the NHWC input / output tensors
+  bool bias;
+  long w_off = -1, b_off = -1;  // float offsets in the flat parameter buffer
+  // packed copies (byte offsets into the workspace weight arena)
+  size_t wf = 0, wd = 0;
+  int Kg, Kpad, rows_f;   // forward pack
+  int Kgd, Kpad_d, rows_d;  // data-gradient pack (rows = Cin_p, K = R*S*Cout_p)
+};
+
+struct BnDesc {
+  std::string name;
+  int C;
+  long g_off, b_off;      // flat parameter buffer
+  long rm_off, rv_off;    // flat running-stat buffer
+};
+
+struct TensorInfo {
+  std::string name;
+  int ndim;
+  long shape[4];
+  long offset;
+  int kind;  // 0 parameter (flat param buffer), 1 running statistic (flat buffer)
+  int stage; // 0 stem, 1..4 encoder layers, 5 decoder, 6 head (gradient bucket id)
+};
+
+struct Unit {  // conv -> BN -> (+ residual) -> ReLU
+  int conv = -1, bn = -1;
+  Act in0, in1;
+  bool up0 = false;
+  Act y, out;
+  float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;
+  bool relu = true;
+  int res_unit = -1;   // downsample unit whose BN output is the residual
+  Act res;             // identity residual
+};
+
+class UNet {
+ public:
+  UNet(int in_channels, int classes, int dtype);
+  int in_channels, classes, dtype;
+  std::vector<ConvDesc> convs;
+  std::vector<BnDesc> bns;
+  std::vector<TensorInfo> tensors;
+  long n_params = 0, n_buffers = 0;
+  long stage_begin[8];  // flat-parameter offset where each stage starts (stage_begin[7] = n_params)
+
+  size_t workspace_bytes(int B, int H, int W, int training);
+
+  // stage entry points; features cross the boundary as NCHW fp32 only in the split path
+  int forward(const float* params, float* buffers, const float* x_nchw, float* logits_nchw, int B, int H, int W,
+              int training, void* ws, size_t ws_bytes, hipStream_t s);
+  // stage_events: optional 7 hipEvent_t recorded on `s` as soon as the gradients of stage k
+  // (6 head, 5 decoder, 4..1 encoder layers, 0 stem) are complete — lets the host overlap the
+  // bucketed RCCL all-reduce with the rest of the backward pass.
+  int backward(const float* params, const float* dlogits_nchw, const void* dlogits_nhwc, float* grads, void* ws,
+               size_t ws_bytes, hipStream_t s, void* const* stage_events = nullptr);
+
+  int encoder_forward(const float* params, float* buffers, const float* x_nchw, float* const feats_nchw[5], int B,
+                      int H, int W, int training, void* ws, size_t ws_bytes, hipStream_t s);
+  int decoder_forward(const float* params, float* buffers, const float* const feats_nchw[5], float* out_nchw, int B,
+                      int H, int W, int training, void* ws, size_t ws_bytes, hipStream_t s);
+  int head_forward(const float* params, const float* x_nchw, float* logits_nchw, int B, int H, int W, int training,
+                   void* ws, size_t ws_bytes, hipStream_t s);
+  int head_backward(const float* params, const float* dlogits_nchw, float* dx_nchw, float* grads, void* ws,
+                    size_t ws_bytes, hipStream_t s);
+  int decoder_backward(const float* params, const float* dout_nchw, float* const dfeats_nchw[5], float* grads,
+                       void* ws, size_t ws_bytes, hipStream_t s);
+  int encoder_backward(const float* params, const float* const dfeats_nchw[5], float* grads, void* ws,
+                       size_t ws_bytes, hipStream_t s);
+
+  void* last_dlogits_nhwc() const { return dl_nhwc_; }
+  int head_ld() const { return 16 > classes ? 16 : (int)round_up(classes, 8); }
+
+ private:
+  // ---- arena
+  unsigned char* base_ = nullptr;
+  size_t cap_ = 0, top_ = 0;
+  bool dry_ = false;
+  int err_ = 0;
+  hipStream_t s_ = nullptr;
+  void* alloc(size_t bytes);
+  Act alloc_act(int N, int H, int W, int C);
+  float* alloc_f(long n) { return (float*)alloc((size_t)n * 4); }
+
+  // ---- per-call state
+  const float* params_ = nullptr;
+  float* buffers_ = nullptr;
+  float* grads_ = nullptr;
+  int B_ = 0, H_ = 0, W_ = 0, training_ = 0;
+  std::vector<Unit> units_;
+  Act xin_, f_[6], dec_in_[6], pool_, dec_out_;
+  unsigned char* pool_idx_ = nullptr;
+  int enc_units_end_ = 0, dec_units_begin_ = 0;
+  size_t fwd_top_ = 0;      // arena top after forward (backward scratch starts here)
+  bool packed_d_ = false;
+  void* dl_nhwc_ = nullptr;
+  void* const* stage_events_ = nullptr;
+  void stage_done(int stage);
+
+  struct GradBuf { void* act; void* g; bool init; };
+  std::vector<GradBuf> gbufs_;
+  void* grad_of(const Act& a, bool* accumulate);
+  void* grad_peek(const Act& a);
+
+  void build_table();
+  int add_conv(const std::string& name, int cin, int cout, int k, int stride, int pad, bool bias, int stage);
+  int add_bn(const std::string& name, int c, int stage);
+  void begin(void* ws, size_t ws_bytes, hipStream_t s, bool dry);
+  void pack_forward_weights();
+  void pack_dgrad_weights();
+  int run_unit(int conv, int bn, const Act& in0, const Act& in1, bool up0, bool relu, int res_unit, const Act& res,
+               bool materialize);
+  void encoder_fwd_impl(const float* x_nchw);
+  void decoder_fwd_impl();
+  void head_fwd_impl(float* logits_nchw);
+  void unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bool need_dgrad, void* dx_override);
+  void head_bwd_impl(const void* dl);
+  void decoder_bwd_impl();
+  void encoder_bwd_impl();
+  void fwd_common_begin(const float* params, float* buffers, int B, int H, int W, int training);
+};
+
+}  // namespace flair

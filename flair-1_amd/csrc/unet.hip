@@ -1,0 +1,576 @@
+// Executor for smp-0.3.3 Unet(resnet34) on gfx950 — see unet.h.
+// Reference call sites replaced: /root/reference/src/flair/model.py:57-64 (encoder / decoder /
+// segmentation_head / whole-model forward) and their autograd backward.
+#include "unet.h"
+
+#include <string.h>
+
+namespace flair {
+
+int conv_weight_rows_pad(int cout);  // conv_igemm.hip
+
+#define RUN(expr)                         \
+  do {                                    \
+    if (!dry_ && !err_) {                 \
+      int rc__ = (expr);                  \
+      if (rc__) err_ = rc__;              \
+    }                                     \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------ table
+int UNet::add_conv(const std::string& name, int cin, int cout, int k, int stride, int pad, bool bias, int stage) {
+  ConvDesc c;
+  c.name = name; c.Cin = cin; c.Cout = cout; c.R = k; c.S = k; c.stride = stride; c.pad = pad; c.bias = bias;
+  c.Cin_p = (int)round_up(cin, 8);
+  c.Cout_p = cout < 16 ? 16 : (int)round_up(cout, 8);
+  c.w_off = n_params;
+  TensorInfo t;
+  t.name = name + ".weight"; t.ndim = 4; t.shape[0] = cout; t.shape[1] = cin; t.shape[2] = k; t.shape[3] = k;
+  t.offset = n_params; t.kind = 0; t.stage = stage;
+  tensors.push_back(t);
+  n_params += (long)cout * cin * k * k;
+  if (bias) {
+    c.b_off = n_params;
+    TensorInfo b;
+    b.name = name + ".bias"; b.ndim = 1; b.shape[0] = cout; b.shape[1] = b.shape[2] = b.shape[3] = 1;
+    b.offset = n_params; b.kind = 0; b.stage = stage;
+    tensors.push_back(b);
+    n_params += cout;
+  }
+  const int kstep = dtype == DT_F32 ? 32 : 64;
+  c.Kg = k * k * c.Cin_p;
+  c.Kpad = (int)round_up(c.Kg, kstep);
+  c.rows_f = conv_weight_rows_pad(cout);
+  c.Kgd = k * k * c.Cout_p;
+  c.Kpad_d = (int)round_up(c.Kgd, kstep);
+  c.rows_d = conv_weight_rows_pad(c.Cin_p);
+  convs.push_back(c);
+  return (int)convs.size() - 1;
+}
+
+int UNet::add_bn(const std::string& name, int C, int stage) {
+  BnDesc b;
+  b.name = name; b.C = C;
+  const char* pn[2] = {".weight", ".bias"};
+  for (int i = 0; i < 2; ++i) {
+    TensorInfo t;
+    t.name = name + pn[i]; t.ndim = 1; t.shape[0] = C; t.shape[1] = t.shape[2] = t.shape[3] = 1;
+    t.offset = n_params; t.kind = 0; t.stage = stage;
+    tensors.push_back(t);
+    (i == 0 ? b.g_off : b.b_off) = n_params;
+    n_params += C;
+  }
+  const char* bn_[2] = {".running_mean", ".running_var"};
+  for (int i = 0; i < 2; ++i) {
+    TensorInfo t;
+    t.name = name + bn_[i]; t.ndim = 1; t.shape[0] = C; t.shape[1] = t.shape[2] = t.shape[3] = 1;
+    t.offset = n_buffers; t.kind = 1; t.stage = stage;
+    tensors.push_back(t);
+    (i == 0 ? b.rm_off : b.rv_off) = n_buffers;
+    n_buffers += C;
+  }
+  bns.push_back(b);
+  return (int)bns.size() - 1;
+}
+
+// Layer order == forward order == flat parameter order, so the gradient of stage k occupies
+// [stage_begin[k], stage_begin[k+1]) and becomes ready in reverse order during backward
+// (bucketed RCCL all-reduce).  Every stage start is padded to 4 floats.
+void UNet::build_table() {
+  auto pad4 = [&]() { n_params = round_up(n_params, 4); };
+  stage_begin[0] = 0;
+  add_conv("encoder.conv1", in_channels, 64, 7, 2, 3, false, 0);
+  add_bn("encoder.bn1", 64, 0);
+  const int planes[4] = {64, 128, 256, 512}, nblk[4] = {3, 4, 6, 3};
+  int inpl = 64;
+  for (int L = 0; L < 4; ++L) {
+    pad4();
+    stage_begin[L + 1] = n_params;
+    for (int b = 0; b < nblk[L]; ++b) {
+      const std::string p = "encoder.layer" + std::to_string(L + 1) + "." + std::to_string(b);
+      const int stride = (b == 0 && L > 0) ? 2 : 1;
+      add_conv(p + ".conv1", inpl, planes[L], 3, stride, 1, false, L + 1);
+      add_bn(p + ".bn1", planes[L], L + 1);
+      add_conv(p + ".conv2", planes[L], planes[L], 3, 1, 1, false, L + 1);
+      add_bn(p + ".bn2", planes[L], L + 1);
+      if (b == 0 && (stride != 1 || inpl != planes[L])) {
+        add_conv(p + ".downsample.0", inpl, planes[L], 1, stride, 0, false, L + 1);
+        add_bn(p + ".downsample.1", planes[L], L + 1);
+      }
+      inpl = planes[L];
+    }
+  }
+  pad4();
+  stage_begin[5] = n_params;
+  const int din[5] = {512, 256, 128, 64, 32}, dskip[5] = {256, 128, 64, 64, 0}, dout[5] = {256, 128, 64, 32, 16};
+  for (int i = 0; i < 5; ++i) {
+    const std::string p = "decoder.blocks." + std::to_string(i);
+    add_conv(p + ".conv1.0", din[i] + dskip[i], dout[i], 3, 1, 1, false, 5);
+    add_bn(p + ".conv1.1", dout[i], 5);
+    add_conv(p + ".conv2.0", dout[i], dout[i], 3, 1, 1, false, 5);
+    add_bn(p + ".conv2.1", dout[i], 5);
+  }
+  pad4();
+  stage_begin[6] = n_params;
+  add_conv("segmentation_head.0", 16, classes, 3, 1, 1, true, 6);
+  pad4();
+  stage_begin[7] = n_params;
+}
+
+UNet::UNet(int in_ch, int cls, int dt) : in_channels(in_ch), classes(cls), dtype(dt) { build_table(); }
+
+// ------------------------------------------------------------------------------------------ arena
+void* UNet::alloc(size_t bytes) {
+  const size_t off = top_;
+  top_ = (size_t)round_up((long)(top_ + bytes), 256);
+  if (!dry_ && top_ > cap_) { if (!err_) err_ = -100; return base_; }
+  return base_ + off;  // dry runs use a fake, never dereferenced base so tensors keep distinct identities
+}
+
+Act UNet::alloc_act(int N, int H, int W, int C) {
+  Act a;
+  a.N = N; a.H = H; a.W = W; a.C = C;
+  a.p = alloc((size_t)a.elems() * dtype_size(dtype));
+  return a;
+}
+
+void UNet::begin(void* ws, size_t ws_bytes, hipStream_t s, bool dry) {
+  base_ = dry ? (unsigned char*)0x100000 : (unsigned char*)ws;
+  cap_ = ws_bytes; top_ = 0; dry_ = dry; err_ = 0; s_ = s;
+  units_.clear();
+  gbufs_.clear();
+  packed_d_ = false;
+  dl_nhwc_ = nullptr;
+  // weight arena
+  for (auto& c : convs) {
+    c.wf = top_; alloc((size_t)c.rows_f * c.Kpad * dtype_size(dtype));
+  }
+  for (auto& c : convs) {
+    c.wd = top_; alloc((size_t)c.rows_d * c.Kpad_d * dtype_size(dtype));
+  }
+}
+
+void UNet::pack_forward_weights() {
+  for (auto& c : convs)
+    RUN(pack_weight(dtype, params_ + c.w_off, base_ + c.wf, c.Cout, c.Cin, c.R, c.S, c.Cin_p, c.rows_f, c.Kpad, 0, s_));
+}
+
+void UNet::pack_dgrad_weights() {
+  if (packed_d_) return;
+  packed_d_ = true;
+  for (size_t i = 1; i < convs.size(); ++i) {  // the stem needs no data gradient
+    auto& c = convs[i];
+    RUN(pack_weight(dtype, params_ + c.w_off, base_ + c.wd, c.Cout, c.Cin, c.R, c.S, c.Cout_p, c.rows_d, c.Kpad_d, 1, s_));
+  }
+}
+
+void* UNet::grad_of(const Act& a, bool* accumulate) {
+  for (auto& g : gbufs_)
+    if (g.act == a.p) { *accumulate = g.init; g.init = true; return g.g; }
+  GradBuf g;
+  g.act = a.p;
+  g.g = alloc((size_t)a.elems() * dtype_size(dtype));
+  g.init = true;
+  *accumulate = false;
+  gbufs_.push_back(g);
+  return g.g;
+}
+
+void* UNet::grad_peek(const Act& a) {
+  for (auto& g : gbufs_)
+    if (g.act == a.p) return g.g;
+  return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+static void fill_conv_args(ConvArgs& a, const ConvDesc& c, const Act& in0, const Act& in1, bool up0, const Act& y,
+                           const void* wpacked) {
+  memset(&a, 0, sizeof(a));
+  a.src0 = in0.p; a.src1 = in1.p;
+  a.C0 = in0.C; a.C1 = in1.p ? in1.C : 0;
+  a.up0 = up0 ? 1 : 0;
+  a.N = in0.N;
+  a.Hin = up0 ? in0.H * 2 : in0.H;
+  a.Win = up0 ? in0.W * 2 : in0.W;
+  a.Hout = y.H; a.Wout = y.W;
+  a.R = c.R; a.S = c.S;
+  a.out_mul = c.stride; a.pad = c.pad; a.in_div = 1;
+  a.Cout = c.Cout;
+  a.Kg = c.Kg; a.Kpad = c.Kpad;
+  a.w = wpacked;
+  a.out = y.p; a.out_ld = y.C;
+}
+
+int UNet::run_unit(int ci, int bi, const Act& in0, const Act& in1, bool up0, bool relu, int res_unit, const Act& res,
+                   bool materialize) {
+  const ConvDesc& c = convs[ci];
+  const BnDesc& b = bns[bi];
+  Unit u;
+  u.conv = ci; u.bn = bi; u.in0 = in0; u.in1 = in1; u.up0 = up0; u.relu = relu; u.res_unit = res_unit; u.res = res;
+  const int Hin = up0 ? in0.H * 2 : in0.H, Win = up0 ? in0.W * 2 : in0.W;
+  const int Ho = (Hin + 2 * c.pad - c.R) / c.stride + 1, Wo = (Win + 2 * c.pad - c.S) / c.stride + 1;
+  u.y = alloc_act(in0.N, Ho, Wo, c.Cout_p);
+  u.scale = alloc_f(b.C); u.shift = alloc_f(b.C); u.mean = alloc_f(b.C); u.invstd = alloc_f(b.C);
+  ConvArgs a;
+  fill_conv_args(a, c, in0, in1, up0, u.y, base_ + c.wf);
+  const int nblk = conv_grid_rows(dtype, a);
+  float* partial = training_ ? alloc_f((long)nblk * 2 * b.C) : nullptr;
+  a.stats = partial;
+  RUN(launch_conv(dtype, a, s_));
+  if (training_)
+    RUN(bn_finalize(partial, nblk, b.C, u.y.rows(), params_ + b.g_off, params_ + b.b_off, buffers_ + b.rm_off,
+                    buffers_ + b.rv_off, 0.1f, 1e-5f, u.scale, u.shift, u.mean, u.invstd, s_));
+  else
+    RUN(bn_eval_coeffs(b.C, params_ + b.g_off, params_ + b.b_off, buffers_ + b.rm_off, buffers_ + b.rv_off, 1e-5f,
+                       u.scale, u.shift, s_));
+  if (materialize) {
+    u.out = alloc_act(in0.N, Ho, Wo, c.Cout_p);
+    const void* rp = nullptr;
+    const float *rs = nullptr, *rh = nullptr;
+    if (res_unit >= 0) { rp = units_[res_unit].y.p; rs = units_[res_unit].scale; rh = units_[res_unit].shift; }
+    else if (res.p) rp = res.p;
+    RUN(bn_act(dtype, u.y.p, u.scale, u.shift, rp, rs, rh, u.out.p, u.y.rows(), b.C, relu ? 1 : 0, s_));
+  }
+  units_.push_back(u);
+  return (int)units_.size() - 1;
+}
+
+void UNet::fwd_common_begin(const float* params, float* buffers, int B, int H, int W, int training) {
+  params_ = params; buffers_ = buffers; B_ = B; H_ = H; W_ = W; training_ = training;
+}
+
+void UNet::encoder_fwd_impl(const float* x_nchw) {
+  xin_ = alloc_act(B_, H_, W_, convs[0].Cin_p);
+  RUN(nchw_f32_to_nhwc(dtype, x_nchw, xin_.p, B_, in_channels, H_, W_, xin_.C, s_));
+  Act none;
+  int ci = 0, bi = 0;
+  int u = run_unit(ci++, bi++, xin_, none, false, true, -1, none, true);
+  f_[1] = units_[u].out;
+  pool_ = alloc_act(B_, f_[1].H / 2, f_[1].W / 2, 64);
+  pool_idx_ = training_ ? (unsigned char*)alloc((size_t)pool_.elems()) : nullptr;
+  RUN(maxpool3x3s2_fwd(dtype, f_[1].p, pool_.p, pool_idx_, B_, f_[1].H, f_[1].W, 64, s_));
+  Act x = pool_;
+  const int nblk[4] = {3, 4, 6, 3};
+  for (int L = 0; L < 4; ++L) {
+    for (int b = 0; b < nblk[L]; ++b) {
+      const bool ds = (b == 0 && L > 0);
+      const int c1 = ci++, b1 = bi++, c2 = ci++, b2 = bi++;
+      int u1 = run_unit(c1, b1, x, none, false, true, -1, none, true);
+      int ud = -1;
+      if (ds) { const int cd = ci++, bd = bi++; ud = run_unit(cd, bd, x, none, false, false, -1, none, false); }
+      int u2 = run_unit(c2, b2, units_[u1].out, none, false, true, ud, ds ? none : x, true);
+      x = units_[u2].out;
+    }
+    f_[L + 2] = x;
+  }
+  enc_units_end_ = (int)units_.size();
+}
+
+void UNet::decoder_fwd_impl() {
+  Act none;
+  dec_units_begin_ = (int)units_.size();
+  int ci = 36, bi = 36;  // decoder convs / bns follow the 36 encoder ones
+  Act x = f_[5];
+  for (int i = 0; i < 5; ++i) {
+    const Act skip = i < 4 ? f_[4 - i] : none;
+    int u1 = run_unit(ci++, bi++, x, skip, true, true, -1, none, true);
+    int u2 = run_unit(ci++, bi++, units_[u1].out, none, false, true, -1, none, true);
+    x = units_[u2].out;
+  }
+  dec_out_ = x;
+}
+
+void UNet::head_fwd_impl(float* logits_nchw) {
+  const ConvDesc& c = convs.back();
+  Act none, y;
+  y.N = dec_out_.N; y.H = dec_out_.H; y.W = dec_out_.W; y.C = c.Cout_p; y.p = nullptr;
+  ConvArgs a;
+  fill_conv_args(a, c, dec_out_, none, false, y, base_ + c.wf);
+  a.out = nullptr;
+  a.out_nchw = logits_nchw;
+  a.bias = params_ + c.b_off;
+  RUN(launch_conv(dtype, a, s_));
+}
+
+int UNet::forward(const float* params, float* buffers, const float* x_nchw, float* logits_nchw, int B, int H, int W,
+                  int training, void* ws, size_t ws_bytes, hipStream_t s) {
+  if ((H % 32) || (W % 32)) return -10;
+  begin(ws, ws_bytes, s, false);
+  fwd_common_begin(params, buffers, B, H, W, training);
+  pack_forward_weights();
+  encoder_fwd_impl(x_nchw);
+  decoder_fwd_impl();
+  head_fwd_impl(logits_nchw);
+  fwd_top_ = top_;
+  return err_;
+}
+
+int UNet::encoder_forward(const float* params, float* buffers, const float* x_nchw, float* const feats[5], int B, int H,
+                          int W, int training, void* ws, size_t ws_bytes, hipStream_t s) {
+  if ((H % 32) || (W % 32)) return -10;
+  begin(ws, ws_bytes, s, false);
+  fwd_common_begin(params, buffers, B, H, W, training);
+  pack_forward_weights();
+  encoder_fwd_impl(x_nchw);
+  for (int i = 0; i < 5; ++i) {
+    const Act& f = f_[i + 1];
+    RUN(nhwc_to_nchw_f32(dtype, f.p, feats[i], f.N, f.C, f.H, f.W, f.C, nullptr, s_));
+  }
+  fwd_top_ = top_;
+  return err_;
+}
+
+int UNet::decoder_forward(const float* params, float* buffers, const float* const feats[5], float* out_nchw, int B, int H,
+                          int W, int training, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (ws != base_ || B != B_ || H != H_ || W != W_) return -11;  // must follow encoder_forward on the same arena
+  s_ = s; training_ = training; params_ = params; buffers_ = buffers;
+  for (int i = 0; i < 5; ++i) {  // re-import: the caller may have modified feats[-1] (model.py:60)
+    Act f = alloc_act(f_[i + 1].N, f_[i + 1].H, f_[i + 1].W, f_[i + 1].C);
+    RUN(nchw_f32_to_nhwc(dtype, feats[i], f.p, f.N, f.C, f.H, f.W, f.C, s_));
+    dec_in_[i + 1] = f;
+  }
+  Act saved[6];
+  for (int i = 1; i <= 5; ++i) { saved[i] = f_[i]; f_[i] = dec_in_[i]; }
+  decoder_fwd_impl();
+  for (int i = 1; i <= 5; ++i) f_[i] = saved[i];
+  RUN(nhwc_to_nchw_f32(dtype, dec_out_.p, out_nchw, dec_out_.N, 16, dec_out_.H, dec_out_.W, dec_out_.C, nullptr, s_));
+  fwd_top_ = top_;
+  return err_;
+}
+
+int UNet::head_forward(const float* params, const float* x_nchw, float* logits_nchw, int B, int H, int W, int training,
+                       void* ws, size_t ws_bytes, hipStream_t s) {
+  if (ws != base_ || B != B_ || H != H_ || W != W_) return -11;
+  s_ = s; params_ = params; training_ = training;
+  Act x = alloc_act(B, H, W, 16);
+  RUN(nchw_f32_to_nhwc(dtype, x_nchw, x.p, B, 16, H, W, 16, s_));
+  dec_out_ = x;
+  head_fwd_impl(logits_nchw);
+  fwd_top_ = top_;
+  return err_;
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// Backward of one conv->BN->(+res)->ReLU unit.  dout = gradient w.r.t. u.out (or w.r.t. the BN
+// output when the unit was not materialised).  Produces parameter gradients, optionally the
+// residual-branch gradient dz (dres) and the input gradient (into grad_of(in0) or dx_override).
+void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bool need_dgrad, void* dx_override) {
+  const Unit& u = units_[ui];
+  const ConvDesc& c = convs[u.conv];
+  const BnDesc& b = bns[u.bn];
+  const long rows = u.y.rows();
+  void* dy = alloc((size_t)u.y.elems() * dtype_size(dtype));
+  float* partial = alloc_f((long)bn_bwd_blocks(rows) * 2 * b.C);
+  float* coef = alloc_f(3 * b.C);
+  RUN(bn_backward(dtype, dout, u.relu ? u.out.p : nullptr, u.y.p, u.mean, u.invstd, params_ + b.g_off, rows, b.C,
+                  partial, coef, grads_ + b.g_off, grads_ + b.b_off, 0, dy, dres, dres_acc ? 1 : 0, s_));
+  // weight gradient
+  WgradArgs w;
+  memset(&w, 0, sizeof(w));
+  w.x0 = u.in0.p; w.x1 = u.in1.p; w.C0 = u.in0.C; w.C1 = u.in1.p ? u.in1.C : 0; w.up0 = u.up0 ? 1 : 0;
+  w.N = u.in0.N; w.Hin = u.up0 ? u.in0.H * 2 : u.in0.H; w.Win = u.up0 ? u.in0.W * 2 : u.in0.W;
+  w.Hout = u.y.H; w.Wout = u.y.W; w.R = c.R; w.S = c.S; w.stride = c.stride; w.pad = c.pad;
+  w.dy = dy; w.dy_ld = u.y.C; w.Cout = c.Cout;
+  w.dw = grads_ + c.w_off; w.Cin_real = c.Cin; w.accumulate = 0;
+  w.partial = (float*)alloc(wgrad_workspace_bytes(dtype, w));
+  RUN(launch_wgrad(dtype, w, s_));
+  if (!need_dgrad) return;
+  // data gradient: gather-form conv over dy with the flipped / transposed pack
+  Act dyact = u.y;
+  dyact.p = dy;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src0 = dy; a.C0 = u.y.C; a.C1 = 0; a.up0 = 0;
+  a.N = u.y.N; a.Hin = u.y.H; a.Win = u.y.W;
+  a.Hout = w.Hin; a.Wout = w.Win;
+  a.R = c.R; a.S = c.S; a.out_mul = 1; a.pad = c.R - 1 - c.pad; a.in_div = c.stride;
+  a.Cout = c.Cin_p;
+  a.Kg = c.Kgd; a.Kpad = c.Kpad_d;
+  a.w = base_ + c.wd;
+  a.out_ld = c.Cin_p;
+  if (dx_override) {
+    a.out = dx_override; a.accumulate = 0;
+  } else {
+    bool acc = false;
+    a.out = grad_of(u.in0, &acc);
+    a.accumulate = acc ? 1 : 0;
+  }
+  RUN(launch_conv(dtype, a, s_));
+}
+
+void UNet::head_bwd_impl(const void* dl) {
+  const ConvDesc& c = convs.back();
+  WgradArgs w;
+  memset(&w, 0, sizeof(w));
+  w.x0 = dec_out_.p; w.C0 = dec_out_.C; w.N = dec_out_.N; w.Hin = dec_out_.H; w.Win = dec_out_.W;
+  w.Hout = dec_out_.H; w.Wout = dec_out_.W; w.R = 3; w.S = 3; w.stride = 1; w.pad = 1;
+  w.dy = dl; w.dy_ld = c.Cout_p; w.Cout = c.Cout; w.dw = grads_ + c.w_off; w.Cin_real = c.Cin;
+  w.partial = (float*)alloc(wgrad_workspace_bytes(dtype, w));
+  RUN(launch_wgrad(dtype, w, s_));
+  // bias gradient = column sums of dl
+  const long rows = dec_out_.rows();
+  float* partial = alloc_f((long)bn_bwd_blocks(rows) * c.Cout_p);
+  RUN(colsum(dtype, dl, rows, c.Cout_p, c.Cout, partial, grads_ + c.b_off, s_));
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src0 = dl; a.C0 = c.Cout_p; a.N = dec_out_.N; a.Hin = dec_out_.H; a.Win = dec_out_.W;
+  a.Hout = dec_out_.H; a.Wout = dec_out_.W; a.R = 3; a.S = 3; a.out_mul = 1; a.pad = 1; a.in_div = 1;
+  a.Cout = c.Cin_p; a.Kg = c.Kgd; a.Kpad = c.Kpad_d; a.w = base_ + c.wd;
+  bool acc = false;
+  a.out = grad_of(dec_out_, &acc);
+  a.out_ld = c.Cin_p; a.accumulate = acc ? 1 : 0;
+  RUN(launch_conv(dtype, a, s_));
+}
+
+void UNet::decoder_bwd_impl() {
+  for (int i = 4; i >= 0; --i) {
+    const int u1 = dec_units_begin_ + 2 * i, u2 = u1 + 1;
+    unit_backward(u2, grad_peek(units_[u2].out), nullptr, false, true, nullptr);
+    // conv1: gradient w.r.t. the virtual concat, then split: 2x2 sum-pool -> x, copy -> skip
+    const Unit& U = units_[u1];
+    const int C0 = U.in0.C, C1 = U.in1.p ? U.in1.C : 0;
+    void* dcat = alloc((size_t)U.y.rows() * (C0 + C1) * dtype_size(dtype));
+    unit_backward(u1, grad_peek(U.out), nullptr, false, true, dcat);
+    bool acc0 = false, acc1 = false;
+    void* dx0 = grad_of(U.in0, &acc0);
+    void* dsk = C1 ? grad_of(U.in1, &acc1) : nullptr;
+    RUN(upcat_bwd(dtype, dcat, dx0, acc0 ? 1 : 0, dsk, acc1 ? 1 : 0, U.y.N, U.y.H, U.y.W, C0, C1, s_));
+  }
+}
+
+void UNet::encoder_bwd_impl() {
+  // walk the encoder units backwards; layout per block: u1, [ud], u2
+  int ui = enc_units_end_ - 1;
+  const int nblk[4] = {3, 4, 6, 3};
+  for (int L = 3; L >= 0; --L) {
+    for (int b = nblk[L] - 1; b >= 0; --b) {
+      const bool ds = (b == 0 && L > 0);
+      const int u2 = ui, ud = ds ? ui - 1 : -1, u1 = ds ? ui - 2 : ui - 1;
+      ui = u1 - 1;
+      const Act& X = units_[u1].in0;
+      const void* dO = grad_peek(units_[u2].out);
+      if (!ds) {
+        bool acc = false;
+        void* dX = grad_of(X, &acc);
+        unit_backward(u2, dO, dX, acc, true, nullptr);   // identity branch: dX (+)= dz2
+      } else {
+        void* dz = alloc((size_t)units_[u2].y.elems() * dtype_size(dtype));
+        unit_backward(u2, dO, dz, false, true, nullptr);
+        unit_backward(ud, dz, nullptr, false, true, nullptr);  // no ReLU on the downsample branch
+      }
+      unit_backward(u1, grad_peek(units_[u1].out), nullptr, false, true, nullptr);
+    }
+    stage_done(L + 1);
+  }
+  // maxpool: d f1 (+)= scatter(d pool)
+  bool acc = false;
+  void* df1 = grad_of(f_[1], &acc);
+  RUN(maxpool3x3s2_bwd(dtype, grad_peek(pool_), pool_idx_, df1, acc ? 1 : 0, B_, f_[1].H, f_[1].W, 64, s_));
+  unit_backward(0, df1, nullptr, false, false, nullptr);  // stem: no data gradient
+  stage_done(0);
+}
+
+void UNet::stage_done(int stage) {
+  if (stage_events_ && stage_events_[stage] && !dry_ && !err_) {
+    hipError_t e = hipEventRecord((hipEvent_t)stage_events_[stage], s_);
+    if (e != hipSuccess) err_ = (int)e;
+  }
+}
+
+int UNet::backward(const float* params, const float* dlogits_nchw, const void* dlogits_nhwc, float* grads, void* ws,
+                   size_t ws_bytes, hipStream_t s, void* const* stage_events) {
+  if (ws != base_ || !training_) return -11;
+  s_ = s; params_ = params; grads_ = grads; top_ = fwd_top_;
+  stage_events_ = stage_events;
+  gbufs_.clear();
+  pack_dgrad_weights();
+  const void* dl = dlogits_nhwc;
+  if (!dl) {
+    const int ld = convs.back().Cout_p;
+    void* t = alloc((size_t)dec_out_.rows() * ld * dtype_size(dtype));
+    RUN(nchw_f32_to_nhwc(dtype, dlogits_nchw, t, B_, classes, H_, W_, ld, s_));
+    dl = t;
+  }
+  head_bwd_impl(dl);
+  stage_done(6);
+  decoder_bwd_impl();
+  stage_done(5);
+  encoder_bwd_impl();
+  stage_events_ = nullptr;
+  return err_;
+}
+
+int UNet::head_backward(const float* params, const float* dlogits_nchw, float* dx_nchw, float* grads, void* ws,
+                        size_t ws_bytes, hipStream_t s) {
+  if (ws != base_ || !training_) return -11;
+  s_ = s; params_ = params; grads_ = grads;
+  pack_dgrad_weights();
+  const int ld = convs.back().Cout_p;
+  void* t = alloc((size_t)dec_out_.rows() * ld * dtype_size(dtype));
+  RUN(nchw_f32_to_nhwc(dtype, dlogits_nchw, t, B_, classes, H_, W_, ld, s_));
+  head_bwd_impl(t);
+  RUN(nhwc_to_nchw_f32(dtype, grad_peek(dec_out_), dx_nchw, B_, 16, H_, W_, 16, nullptr, s_));
+  return err_;
+}
+
+int UNet::decoder_backward(const float* params, const float* dout_nchw, float* const dfeats[5], float* grads, void* ws,
+                           size_t ws_bytes, hipStream_t s) {
+  if (ws != base_ || !training_) return -11;
+  s_ = s; params_ = params; grads_ = grads;
+  pack_dgrad_weights();
+  const Act& out = units_.back().out;  // decoder output (last unit)
+  bool acc = false;
+  void* g = grad_of(out, &acc);
+  RUN(nchw_f32_to_nhwc(dtype, dout_nchw, g, out.N, 16, out.H, out.W, out.C, s_));
+  decoder_bwd_impl();
+  for (int i = 0; i < 5; ++i) {
+    const Act& f = dec_in_[i + 1];
+    RUN(nhwc_to_nchw_f32(dtype, grad_peek(f), dfeats[i], f.N, f.C, f.H, f.W, f.C, nullptr, s_));
+  }
+  return err_;
+}
+
+int UNet::encoder_backward(const float* params, const float* const dfeats[5], float* grads, void* ws, size_t ws_bytes,
+                           hipStream_t s) {
+  if (ws != base_ || !training_) return -11;
+  s_ = s; params_ = params; grads_ = grads;
+  pack_dgrad_weights();
+  for (int i = 0; i < 5; ++i) {
+    const Act& f = f_[i + 1];
+    bool acc = false;
+    void* g = grad_of(f, &acc);
+    if (acc) { if (!err_) err_ = -12; }
+    RUN(nchw_f32_to_nhwc(dtype, dfeats[i], g, f.N, f.C, f.H, f.W, f.C, s_));
+  }
+  encoder_bwd_impl();
+  return err_;
+}
+
+// Upper bound of the arena: dry run of the split sequence (superset of the fused one).
+size_t UNet::workspace_bytes(int B, int H, int W, int training) {
+  begin(nullptr, 0, nullptr, true);
+  fwd_common_begin(nullptr, nullptr, B, H, W, training);
+  encoder_fwd_impl(nullptr);
+  for (int i = 1; i <= 5; ++i) dec_in_[i] = alloc_act(f_[i].N, f_[i].H, f_[i].W, f_[i].C);
+  decoder_fwd_impl();
+  alloc_act(B, H, W, 16);
+  head_fwd_impl(nullptr);
+  if (training) {
+    alloc((size_t)dec_out_.rows() * convs.back().Cout_p * dtype_size(dtype));
+    grads_ = nullptr;
+    head_bwd_impl(nullptr);
+    bool acc;
+    grad_of(units_.back().out, &acc);
+    decoder_bwd_impl();
+    for (int i = 1; i <= 5; ++i) alloc((size_t)f_[i].elems() * dtype_size(dtype));
+    encoder_bwd_impl();
+  }
+  const size_t need = top_ + (1 << 20);
+  dry_ = false;
+  base_ = nullptr;
+  units_.clear();
+  gbufs_.clear();
+  return need;
+}
+
+}  // namespace flair

@@ -1,0 +1,139 @@
+/* flair_hip.h — C ABI of the MI355X-native FLAIR-1 segmentation hot path (libflair_hip.so).
+ *
+ * Drop-in boundary.  The reference is Python; the calls a maintainer would bind
+ * (ctypes) are listed next to the reference interface each one replaces.
+ * Conventions: plain pointers and sizes only, no torch types; every pointer is DEVICE memory unless
+ * marked host; every function enqueues work on `stream` (a hipStream_t passed as void*) and never
+ * synchronises, allocates or frees device memory; return value 0 = ok, >0 = hipError_t,
+ * <0 = argument error (flair_strerror).  Tensors at the boundary use the reference's layouts:
+ * images / logits / features NCHW fp32, labels (B,H,W), parameters PyTorch OIHW fp32.
+ * Internally activations are NHWC in `dtype` (0 = fp32 parity mode, 1 = bf16 throughput mode).
+ */
+#ifndef FLAIR_HIP_H
+#define FLAIR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLAIR_DT_F32 0
+#define FLAIR_DT_BF16 1
+
+const char* flair_strerror(int code);
+int flair_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model object.  Replaces smp.create_model(arch='unet', encoder_name='resnet34', classes, in_channels)
+ * — /root/reference/src/flair/model.py:37-41 and src/zone_detect/model.py:34-39.
+ * The handle holds only host-side metadata (layer table, arena plan); parameters stay in the
+ * caller's flat fp32 buffers laid out as flair_unet_tensor_info describes (names = smp-0.3.3
+ * state_dict keys). */
+typedef struct flair_unet flair_unet_t;
+int flair_unet_create(flair_unet_t** out, int in_channels, int classes, int dtype);
+void flair_unet_destroy(flair_unet_t* h);
+int64_t flair_unet_param_count(const flair_unet_t* h);   /* floats in the flat parameter / gradient buffer */
+int64_t flair_unet_buffer_count(const flair_unet_t* h);  /* floats in the flat BN running-stat buffer */
+int flair_unet_num_tensors(const flair_unet_t* h);
+/* kind: 0 = parameter (offset into params/grads), 1 = running statistic (offset into buffers);
+ * stage: 0 stem, 1-4 encoder layers, 5 decoder, 6 head — contiguous gradient buckets. */
+int flair_unet_tensor_info(const flair_unet_t* h, int i, char* name, int name_cap, int64_t shape[4], int* ndim,
+                           int64_t* offset, int* kind, int* stage);
+int flair_unet_stage_range(const flair_unet_t* h, int stage, int64_t* begin, int64_t* end);
+int64_t flair_unet_workspace_bytes(flair_unet_t* h, int B, int H, int W, int training);
+
+/* seg_model(x)  — model.py:64 (and zone_detect/compare.py:31).  training != 0: BatchNorm batch
+ * statistics + running-stat update in `buffers`, activations kept in `workspace` for backward. */
+int flair_unet_forward(flair_unet_t* h, const float* params, float* buffers, const float* x_nchw, float* logits_nchw,
+                       int B, int H, int W, int training, void* workspace, size_t workspace_bytes, void* stream);
+/* autograd backward of the call above (Lightning's loss.backward(), task_module.py:82-86).
+ * Exactly one of dlogits_nchw (fp32 (B,C,H,W)) / dlogits_nhwc (as written by flair_ce_head with
+ * flair_unet_head_ld) is non-null.  Writes every parameter gradient into `grads` (flat, OIHW).
+ * stage_events: optional array of 7 hipEvent_t (null = none); event k is recorded on `stream` as soon as
+ * the gradients of bucket k (flair_unet_stage_range) are final — ready order 6,5,4,3,2,1,0 — so the
+ * host can start the RCCL all-reduce of a bucket while the rest of backward still runs. */
+int flair_unet_backward(flair_unet_t* h, const float* params, const float* dlogits_nchw, const void* dlogits_nhwc,
+                        float* grads, void* workspace, size_t workspace_bytes, void* stream,
+                        void* const* stage_events);
+int flair_unet_head_ld(const flair_unet_t* h);
+
+/* seg_model.encoder(x) / .decoder(*feats) / .segmentation_head(t) — the metadata path model.py:57-62.
+ * feats[i] = feature i+1 of the encoder, NCHW fp32: (B,64,H/2,W/2) ... (B,512,H/32,W/32). */
+int flair_unet_encoder_forward(flair_unet_t* h, const float* params, float* buffers, const float* x_nchw,
+                               float* const feats_nchw[5], int B, int H, int W, int training, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int flair_unet_decoder_forward(flair_unet_t* h, const float* params, float* buffers, const float* const feats_nchw[5],
+                               float* out_nchw, int B, int H, int W, int training, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int flair_unet_head_forward(flair_unet_t* h, const float* params, const float* x_nchw, float* logits_nchw, int B, int H,
+                            int W, int training, void* workspace, size_t workspace_bytes, void* stream);
+int flair_unet_head_backward(flair_unet_t* h, const float* params, const float* dlogits_nchw, float* dx_nchw,
+                             float* grads, void* workspace, size_t workspace_bytes, void* stream);
+int flair_unet_decoder_backward(flair_unet_t* h, const float* params, const float* dout_nchw,
+                                float* const dfeats_nchw[5], float* grads, void* workspace, size_t workspace_bytes,
+                                void* stream);
+int flair_unet_encoder_backward(flair_unet_t* h, const float* params, const float* const dfeats_nchw[5], float* grads,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused per-pixel head.  Replaces, in one pass over the logits,
+ *   targets = argmax(msk, 1); loss = criterion(logits, targets)            task_module.py:71-72
+ *   nn.CrossEntropyLoss(weight) mean reduction                              tasks_utils.py:88-93
+ *   preds = argmax(softmax(logits, 1), 1)                                   task_module.py:75-76
+ *   MulticlassJaccardIndex.update: confmat += bincount(target*C + pred)     task_module.py:85,107-108
+ * label_kind: 0 uint8 (B,H,W), 1 int32, 2 int64, 3 fp32 one-hot (B,C,H,W) (the reference's batch["msk"]).
+ * Outputs are optional (null = skip).  workspace: flair_ce_workspace_bytes(). */
+size_t flair_ce_workspace_bytes(int B, int H, int W);
+int flair_ce_head(const float* logits_nchw, const void* labels, int label_kind, const float* class_weight, int B, int C,
+                  int H, int W, float* loss, float* dlogits_nchw, void* dlogits_nhwc, int dlogits_dtype, int dlogits_ld,
+                  uint8_t* preds_u8, int64_t* preds_i64, int32_t* targets_i32, int64_t* confmat, void* workspace,
+                  void* stream);
+/* predict_step: argmax(softmax(logits)) — task_module.py:211-212; with maxprob also
+ * zone_detect inference + convert('argmax') — src/zone_detect/compare.py:35, dataset.py:23-30. */
+int flair_softmax_argmax(const float* logits_nchw, int B, int C, int H, int W, uint8_t* preds_u8, int64_t* preds_i64,
+                         float* maxprob, void* stream);
+/* confmat[target][pred] += 1 — torchmetrics update / sklearn confusion_matrix at src/flair/metrics.py:67-71.
+ * kinds: 0 uint8, 1 int32, 2 int64. */
+int flair_confmat_update(const void* target, int target_kind, const void* pred, int pred_kind, int64_t n, int C,
+                         int64_t* confmat, void* stream);
+/* MulticlassJaccardIndex.compute (average None / 'weighted' / 'macro') — task_module.py:36-51,90,113-114. */
+int flair_jaccard(const int64_t* confmat, int C, float* per_class, float* weighted, float* macro, void* stream);
+
+/* torch.optim.SGD(lr) step, no momentum / weight decay — tasks_utils.py:95. */
+int flair_sgd_step(float* params, const float* grads, int64_t n, float lr, void* stream);
+/* feats[-1] += x_enc.unsqueeze(1).unsqueeze(-1).repeat(1,512,1,16) — model.py:59-60: x (N,C,H,W) += v (N,H). */
+int flair_add_rowvec_nchw(float* x, const float* v, int N, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator-level entry points (unit parity tests; same kernels the model object launches).
+ * Activations NHWC in `dtype`; weights PyTorch OIHW fp32. */
+size_t flair_conv2d_workspace_bytes(int dtype, int N, int H, int W, int C0, int C1, int up0, int Cout, int R,
+                                    int stride, int pad);
+/* y = conv2d(cat([up2(x0)?, x1]), w) (+bias); optional fp32 NCHW copy; optional BN batch statistics
+ * (sum, sum of squares per channel, reduced) into stats[2][Cout]. */
+int flair_conv2d_forward(int dtype, const void* x0, const void* x1, int N, int H, int W, int C0, int C1, int up0,
+                         const float* w_oihw, const float* bias, int Cout, int R, int stride, int pad, void* y_nhwc,
+                         float* y_nchw, float* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* dx = conv2d_backward_data(dy, w); dw = conv2d_backward_weight(x, dy) */
+int flair_conv2d_backward(int dtype, const void* x0, int N, int H, int W, int Cin, const float* w_oihw, int Cout, int R,
+                          int stride, int pad, const void* dy_nhwc, void* dx_nhwc, float* dw_oihw, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int flair_bn_relu_forward(int dtype, const void* y, int64_t rows, int C, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int training, const void* residual, int relu,
+                          void* out, float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int flair_bn_relu_backward(int dtype, const void* dout, const void* out, const void* y, int64_t rows, int C,
+                           const float* gamma, const float* save_mean, const float* save_invstd, int relu, void* dy,
+                           void* dres, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int flair_maxpool_forward(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int flair_maxpool_backward(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C,
+                           void* stream);
+int flair_nchw_to_nhwc(int dtype, const float* x_nchw, void* y_nhwc, int N, int C, int H, int W, int Cpad, void* stream);
+int flair_nhwc_to_nchw(int dtype, const void* x_nhwc, float* y_nchw, int N, int C, int H, int W, int Cpad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLAIR_HIP_H */

@@ -1,0 +1,277 @@
+"""Whole-path parity on the GPU: the HIP U-Net/ResNet34 behind the smp surface vs the CPU oracle
+(oracle/unet_resnet34.py + oracle/seg_step.py) and vs the golden vectors made from the reference's own
+model.py / task_module.py (tests/golden/make_golden.py).
+
+Tolerances (north_star): fp32 mode logits within 1e-3 absolute; argmax masks bit-exact wherever the
+oracle's top-2 probability gap exceeds 1e-5 (summation order differs between MKL-DNN and the MFMA
+fp32 FMA chain, so exact ties may flip) with the flip count reported and bounded; bf16 mode is a
+throughput mode judged by loss / mIoU closeness, never bit-exactness.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+CLASSES19 = {1: [1, 'building'], 2: [1, 'pervious surface'], 3: [1, 'impervious surface'], 4: [1, 'bare soil'],
+             5: [1, 'water'], 6: [1, 'coniferous'], 7: [1, 'deciduous'], 8: [1, 'brushwood'], 9: [1, 'vineyard'],
+             10: [1, 'herbaceous vegetation'], 11: [1, 'agricultural land'], 12: [1, 'plowed land'],
+             13: [1, 'swimming_pool'], 14: [1, 'snow'], 15: [0, 'clear cut'], 16: [0, 'mixed'], 17: [0, 'ligneous'],
+             18: [1, 'greenhouse'], 19: [0, 'other']}
+
+
+def _config(n_ch, classes, use_metadata=False):
+    return {"model_framework": {"model_provider": "SegmentationModelsPytorch",
+                                "SegmentationModelsPytorch": {"encoder_decoder": "resnet34_unet", "encoder_weights": None}},
+            "use_metadata": use_metadata, "channels": list(range(1, n_ch + 1)), "classes": classes}
+
+
+def _pair(in_ch, classes, seed, dev, dtype="f32"):
+    """Oracle model (CPU) and the HIP model loaded with the same seeded weights."""
+    import flair_amd
+    from oracle import unet_resnet34 as om
+    ref = om.seeded_model(in_ch, classes, seed)
+    hip = flair_amd.create_model("unet", "resnet34", encoder_weights=None, in_channels=in_ch, classes=classes, compute_dtype=dtype)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    return ref, hip.to(dev)
+
+
+def _mask_agreement(logits_ref, preds_hip):
+    probs = torch.softmax(logits_ref, 1)
+    top2 = probs.topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 1e-5
+    ref = probs.argmax(1)
+    bad_decided = int(((ref != preds_hip) & decided).sum())
+    flips = int((ref != preds_hip).sum())
+    return bad_decided, flips, ref.numel()
+
+
+def test_golden_train_step_fp32(dev, golden_dir):
+    """One training step (forward, weighted CE, backward, SGD lr .02) against the vector produced by the
+    reference's FLAIR_ModelFactory + segmentation_task_training.step on the oracle model."""
+    import flair_amd
+    from oracle import unet_resnet34 as om
+    g = np.load(os.path.join(golden_dir, "step_c13_b2_64.npz"))
+    C = 13
+    classes = {k: CLASSES19[k] for k in range(1, C + 1)}
+    torch.manual_seed(int(g["seed"]))
+    ref = om.create_model("unet", "resnet34", in_channels=5, classes=C)  # same RNG stream as make_golden.py
+    model = flair_amd.FLAIR_ModelFactory(_config(5, classes), compute_dtype="f32")
+    model.seg_model.load_state_dict(ref.state_dict(), strict=True)
+    model = model.to(dev)
+    assert sum(p.numel() for p in model.seg_model.parameters()) == int(g["n_params"]) == 24_444_381
+    img = torch.from_numpy(g["img"]).to(dev)
+    lab = torch.from_numpy(g["lab"]).long()
+    msk = torch.stack([(lab == i) for i in range(C)], 1).float().to(dev)
+    weight = torch.from_numpy(g["weight"])
+    task = flair_amd.segmentation_task_training(model=model, class_infos=classes, criterion=nn.CrossEntropyLoss(weight=weight),
+                                                optimizer=None, use_metadata=False, scheduler=None).to(dev)
+    task.train()
+    logits = task.forward(img, "")
+    loss, preds, targets = flair_amd.task_module.fused_step(logits, msk, task.criterion)
+    lg = logits.detach().cpu()
+    assert (lg - torch.from_numpy(g["logits"])).abs().max() < 1e-3
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    assert torch.equal(targets.cpu().to(torch.uint8), torch.from_numpy(g["targets"]))
+    bad, flips, n = _mask_agreement(torch.from_numpy(g["logits"]), preds.cpu().view(2, 64, 64))
+    assert bad == 0 and flips <= n // 10000 + 1, (bad, flips)
+    assert torch.equal(preds.cpu().to(torch.uint8), torch.from_numpy(g["preds"])) or flips > 0
+    loss.backward()
+    named = dict(model.seg_model.named_parameters())
+    for k, v in zip(g["grad_keys"], g["grad_abs_sum"]):
+        got = float(named[str(k)].grad.double().abs().sum())
+        assert abs(got - v) <= 2e-3 * abs(v) + 1e-6, (k, got, v)
+    torch.optim.SGD(model.parameters(), lr=float(g["lr"])).step()
+    sd = model.seg_model.state_dict()
+    for k, v in zip(g["post_keys"], g["post_abs_sum"]):
+        got = float(sd[str(k)].double().abs().sum())
+        assert abs(got - v) <= 1e-4 * abs(v) + 1e-6, (k, got, v)
+
+
+def test_train_step_matches_oracle_elementwise_fp32(dev):
+    """Element-wise gradient parity (not only checksums) on a 2x5x96x64 batch, incl. BN running stats."""
+    from oracle import seg_step
+    ref, hip = _pair(5, 13, 123, dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 5, 96, 64, generator=g)
+    lab = torch.randint(0, 13, (2, 96, 64), generator=g)
+    ref.train(); hip.train()
+    lr_ = ref(x)
+    loss_r = nn.functional.cross_entropy(lr_, lab)
+    loss_r.backward()
+    lh = hip(x.to(dev))
+    loss_h = nn.functional.cross_entropy(lh, lab.to(dev))
+    loss_h.backward()
+    assert (lh.detach().cpu() - lr_.detach()).abs().max() < 1e-3
+    refp = dict(ref.named_parameters())
+    worst = 0.0
+    for k, p in hip.named_parameters():
+        gr = refp[k].grad
+        err = float((p.grad.cpu() - gr).abs().max() / (gr.abs().max() + 1e-8))
+        worst = max(worst, err)
+        assert err < 5e-3, (k, err)
+    for k, b in hip.named_buffers():
+        rb = dict(ref.named_buffers())[k]
+        assert torch.allclose(b.cpu().float(), rb.float(), rtol=1e-4, atol=1e-5), k
+    seg_step.sgd_step_(ref.parameters(), 0.02)
+    torch.optim.SGD(hip.parameters(), lr=0.02).step()
+    for k, p in hip.named_parameters():
+        assert torch.allclose(p.detach().cpu(), refp[k].detach(), rtol=1e-4, atol=1e-5), k
+
+
+def test_golden_predict_512_fp32(dev, golden_dir):
+    """predict_step on one 512x512 tile in eval mode (running statistics after two training forwards)."""
+    import flair_amd
+    from oracle import unet_resnet34 as om
+    gs = np.load(os.path.join(golden_dir, "step_c13_b2_64.npz"))
+    gp = np.load(os.path.join(golden_dir, "predict_c13_512.npz"))
+    torch.manual_seed(int(gs["seed"]))
+    ref = om.create_model("unet", "resnet34", in_channels=5, classes=13)
+    hip = flair_amd.create_model("unet", "resnet34", encoder_weights=None, in_channels=5, classes=13, compute_dtype="f32")
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(dev)
+    # replay make_golden.py: two training forwards + one SGD step, on the HIP path
+    img = torch.from_numpy(gs["img"]).to(dev)
+    lab = torch.from_numpy(gs["lab"]).long()
+    msk = torch.stack([(lab == i) for i in range(13)], 1).float().to(dev)
+    crit = nn.CrossEntropyLoss(weight=torch.from_numpy(gs["weight"]))
+    hip.train()
+    loss, _, _ = flair_amd.task_module.fused_step(hip(img), msk, crit)
+    loss.backward()
+    with torch.no_grad():
+        hip(img)  # the golden script's second forward (running stats updated twice)
+    torch.optim.SGD(hip.parameters(), lr=0.02).step()
+    task = flair_amd.segmentation_task_predict(model=lambda im, met: hip(im), num_classes=13)
+    hip.eval()
+    tile = torch.randn(1, 5, 512, 512, generator=torch.Generator().manual_seed(int(gp["tile_seed"])))
+    with torch.no_grad():
+        out = task.predict_step({"img": tile.to(dev), "id": ["x"]}, 0)
+        lg = hip(tile.to(dev)).cpu()
+    assert sorted(out.keys()) == ["id", "img", "preds"] and out["preds"].dtype == torch.int64
+    assert np.abs(lg[0, :, 240:272, 240:272].numpy() - gp["logits_crop"]).max() < 1e-3
+    assert np.abs(lg.double().mean(dim=(0, 2, 3)).numpy() - gp["logits_mean"]).max() < 1e-4
+    mism = int((out["preds"].cpu().numpy().astype(np.uint8) != gp["preds"]).sum())
+    assert mism <= 3, mism  # bit-exact up to exact-tie flips
+
+
+def test_golden_metadata_path_fp32(dev, golden_dir):
+    """encoder -> metadata add -> decoder -> head (model.py:57-62) in eval mode, 19 classes, 512x512."""
+    import flair_amd
+    from oracle import unet_resnet34 as om
+    gm = np.load(os.path.join(golden_dir, "metadata_c19_512.npz"))
+    torch.manual_seed(2023)
+    # make_golden.py: FLAIR_ModelFactory.__init__ builds MetadataMLP first, then the U-Net, under seed 2023
+    enc_ref = flair_amd.MetadataMLP()
+    ref = om.create_model("unet", "resnet34", in_channels=5, classes=19)
+    model = flair_amd.FLAIR_ModelFactory(_config(5, CLASSES19, use_metadata=True), compute_dtype="f32")
+    model.enc.load_state_dict(enc_ref.state_dict())
+    model.seg_model.load_state_dict(ref.state_dict())
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(int(gm["tile_seed"]))
+    tile = torch.randn(1, 5, 512, 512, generator=g)
+    mtd = torch.from_numpy(gm["mtd"])
+    with torch.no_grad():
+        assert np.abs(model.enc(mtd.to(dev)).cpu().numpy() - gm["x_enc"]).max() < 1e-5
+        lg = model(tile.to(dev), mtd.to(dev)).cpu()
+    scale = np.abs(gm["logits_crop"]).max()
+    assert np.abs(lg[0, :, 100:132, 300:332].numpy() - gm["logits_crop"]).max() < 1e-3 * max(1.0, scale)
+    assert np.abs(lg.double().mean(dim=(0, 2, 3)).numpy() - gm["logits_mean"]).max() < 1e-3
+
+
+def test_split_path_training_matches_fused(dev):
+    """encoder/decoder/head called separately (with a metadata add in between) give the same gradients
+    as autograd through the oracle."""
+    import flair_amd
+    from oracle import unet_resnet34 as om
+    ref = om.seeded_model(5, 13, 77)
+    model = flair_amd.FLAIR_ModelFactory(_config(5, {k: CLASSES19[k] for k in range(1, 14)}, use_metadata=True), compute_dtype="f32")
+    model.seg_model.load_state_dict(ref.state_dict())
+    model = model.to(dev).train()
+    model.enc.eval()  # dropout off for parity (quirk Q5)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(1, 5, 512, 512, generator=g)
+    mtd = torch.rand(1, 45, generator=g)
+    lab = torch.randint(0, 13, (1, 512, 512), generator=g)
+    out = model(x.to(dev), mtd.to(dev))
+    nn.functional.cross_entropy(out, lab.to(dev)).backward()
+    # oracle with the reference's own fusion arithmetic (model.py:57-62)
+    import copy
+    enc_cpu = copy.deepcopy(model.enc).cpu()
+    ref.train()
+    feats = ref.encoder(x)
+    x_enc = enc_cpu(mtd).unsqueeze(1).unsqueeze(-1).repeat(1, 512, 1, 16)
+    feats[-1] = torch.add(feats[-1], x_enc)
+    o = ref.segmentation_head(ref.decoder(*feats))
+    nn.functional.cross_entropy(o, lab).backward()
+    assert (out.detach().cpu() - o.detach()).abs().max() < 1e-3
+    refp = dict(ref.named_parameters())
+    for k, p in model.seg_model.named_parameters():
+        gr = refp[k].grad
+        assert float((p.grad.cpu() - gr).abs().max() / (gr.abs().max() + 1e-8)) < 5e-3, k
+    for (k, p), (_, q) in zip(model.enc.named_parameters(), enc_cpu.named_parameters()):
+        assert torch.allclose(p.grad.cpu(), q.grad, rtol=1e-3, atol=1e-6), k
+
+
+def test_bf16_throughput_mode_tracks_fp32(dev):
+    """bf16 mode: same step on the same weights stays close in loss and mIoU (not bit-exact by design)."""
+    import flair_amd
+    from oracle import seg_step
+    ref, hip32 = _pair(5, 13, 31, dev, "f32")
+    _, hip16 = _pair(5, 13, 31, dev, "bf16")
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 5, 128, 128, generator=g).to(dev)
+    lab = torch.randint(0, 13, (4, 128, 128), generator=g).to(dev)
+    res = {}
+    for name, m in (("f32", hip32), ("bf16", hip16)):
+        tr = flair_amd.SegTrainer(m.train(), lr=0.02)
+        losses = [tr.train_step(x, lab.to(torch.uint8)).item() for _ in range(3)]
+        cm = tr.confmat.cpu().numpy()
+        res[name] = (losses, seg_step.jaccard_from_confmat(cm, "weighted"), tr.predict(x).cpu())
+    l32, l16 = res["f32"][0], res["bf16"][0]
+    assert all(abs(a - b) < 0.05 * abs(a) for a, b in zip(l32, l16)), (l32, l16)
+    assert l32[-1] < l32[0]  # SGD makes progress on a fixed batch
+    assert abs(res["f32"][1] - res["bf16"][1]) < 0.02
+    agree = float((res["f32"][2] == res["bf16"][2]).float().mean())
+    assert agree > 0.9, agree
+
+
+def test_trainer_matches_autograd_path_fp32(dev):
+    """SegTrainer.train_step (fused C path) == autograd path + torch SGD, bit for bit on the weights."""
+    import flair_amd
+    _, a = _pair(5, 13, 5, dev)
+    _, b = _pair(5, 13, 5, dev)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 5, 64, 64, generator=g).to(dev)
+    lab = torch.randint(0, 13, (2, 64, 64), generator=g).to(dev)
+    w = torch.linspace(0.5, 2, 13)
+    tr = flair_amd.SegTrainer(a.train(), lr=0.02, class_weight=w)
+    la = tr.train_step(x, lab.to(torch.uint8))
+    crit = flair_amd.FusedCrossEntropyLoss(weight=w).to(dev)
+    b.train()
+    lb = crit(b(x), lab)
+    lb.backward()
+    torch.optim.SGD(b.parameters(), lr=0.02).step()
+    assert abs(la.item() - lb.item()) < 1e-6
+    assert torch.allclose(a.flat_parameters(), b.flat_parameters(), rtol=0, atol=1e-7)
+    assert torch.equal(crit.last_preds.to(torch.uint8), tr._preds)
+
+
+def test_errors_and_contract(dev):
+    import flair_amd
+    from flair_amd._lib import FlairHipError
+    m = flair_amd.create_model("unet", "resnet34", encoder_weights=None, in_channels=5, classes=13)
+    with pytest.raises(FlairHipError):
+        m(torch.zeros(1, 5, 64, 64))  # host tensors are refused: no CPU fallback
+    m = m.to(dev)
+    with pytest.raises(RuntimeError, match="divisible by 32"):
+        m(torch.zeros(1, 5, 70, 64, device=dev))
+    with pytest.raises(KeyError):
+        flair_amd.create_model("fpn", "resnet34")
+    with pytest.raises(KeyError):
+        flair_amd.create_model("unet", "resnet50")
+    assert any(isinstance(x, nn.BatchNorm2d) for x in m.modules())
+    feats = m.eval().encoder(torch.zeros(1, 5, 64, 64, device=dev))
+    assert [tuple(f.shape[1:]) for f in feats] == [(5, 64, 64), (64, 32, 32), (64, 16, 16), (128, 8, 8), (256, 4, 4), (512, 2, 2)]
