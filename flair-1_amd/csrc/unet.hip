@@ -551,9 +551,15 @@ size_t UNet::workspace_bytes(int B, int H, int W, int training) {
   begin(nullptr, 0, nullptr, true);
   fwd_common_begin(nullptr, nullptr, B, H, W, training);
   encoder_fwd_impl(nullptr);
-  for (int i = 1; i <= 5; ++i) dec_in_[i] = alloc_act(f_[i].N, f_[i].H, f_[i].W, f_[i].C);
+  Act saved[6];
+  for (int i = 1; i <= 5; ++i) {
+    dec_in_[i] = alloc_act(f_[i].N, f_[i].H, f_[i].W, f_[i].C);
+    saved[i] = f_[i];
+    f_[i] = dec_in_[i];
+  }
   decoder_fwd_impl();
-  alloc_act(B, H, W, 16);
+  for (int i = 1; i <= 5; ++i) f_[i] = saved[i];
+  dec_out_ = alloc_act(B, H, W, 16);
   head_fwd_impl(nullptr);
   if (training) {
     alloc((size_t)dec_out_.rows() * convs.back().Cout_p * dtype_size(dtype));
@@ -562,7 +568,7 @@ size_t UNet::workspace_bytes(int B, int H, int W, int training) {
     bool acc;
     grad_of(units_.back().out, &acc);
     decoder_bwd_impl();
-    for (int i = 1; i <= 5; ++i) alloc((size_t)f_[i].elems() * dtype_size(dtype));
+    for (int i = 1; i <= 5; ++i) grad_of(f_[i], &acc);
     encoder_bwd_impl();
   }
   const size_t need = top_ + (1 << 20);

@@ -1,0 +1,151 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/flair_hip.h declares; host-side
+logic (layout, buckets, sharding) and the N>1 gradient exchange on gloo with world_size 2."""
+import ctypes
+import os
+import re
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "flair_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(flair_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from flair_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 30
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(_lib.PROTOTYPES) == syms  # the Python binding covers exactly the header
+    l = _lib.lib()
+    assert l.flair_version() == 1 and l.flair_strerror(-10).decode().startswith("Wrong input shape")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from flair_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libflair_hip.so")
+    with pytest.raises(_lib.FlairHipError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_host_tensors_are_refused():
+    import flair_amd
+    from flair_amd._lib import FlairHipError
+    m = flair_amd.create_model("unet", "resnet34", encoder_weights=None, in_channels=5, classes=13)
+    with pytest.raises(FlairHipError):
+        m(torch.zeros(1, 5, 64, 64))
+    with pytest.raises(FlairHipError):
+        flair_amd.FusedCrossEntropyLoss()(torch.zeros(1, 13, 8, 8), torch.zeros(1, 8, 8, dtype=torch.long))
+
+
+def test_native_layout_matches_smp_state_dict(golden_dir):
+    import json
+    import flair_amd
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys_c3_cls1.json")))
+    m = flair_amd.create_model("unet", "resnet34", encoder_weights=None, in_channels=3, classes=1)
+    sd = m.state_dict()
+    assert [k for k, _ in keys] == list(sd.keys()) and all(list(sd[k].shape) == s for k, s in keys)
+    assert sum(p.numel() for p in m.parameters()) == 24_436_369
+    lay = m._layout
+    assert set(lay) == {k for k, _ in keys if not k.endswith("num_batches_tracked")}
+    # stages are contiguous, ordered, 16-byte aligned and cover every parameter exactly once
+    sr = m.stage_ranges()
+    assert sr[0][0] == 0 and all(a[1] == b[0] for a, b in zip(sr, sr[1:])) and all(b % 4 == 0 for b, _ in sr)
+    for name, (shape, off, kind, stage) in lay.items():
+        if kind == 0:
+            n = 1
+            for s in shape:
+                n *= s
+            assert sr[stage][0] <= off and off + n <= sr[stage][1], name
+    # smp semantics of the factory
+    with pytest.raises(KeyError):
+        flair_amd.create_model("linknet", "resnet34")
+    with pytest.warns(UserWarning, match="pretrained"):
+        flair_amd.create_model("unet", "resnet34", in_channels=5, classes=13)  # default 'imagenet' is offline
+    # pickling drops the native handle and rebuilds it
+    import pickle
+    m2 = pickle.loads(pickle.dumps(m))
+    assert torch.equal(m2.state_dict()["encoder.conv1.weight"], sd["encoder.conv1.weight"])
+
+
+def test_workspace_plan_scales_and_is_deterministic():
+    import flair_amd
+    from flair_amd import _lib as L
+    m = flair_amd.create_model("unet", "resnet34", encoder_weights=None, in_channels=5, classes=13, compute_dtype="bf16")
+    a = L.lib().flair_unet_workspace_bytes(m._h, 2, 64, 64, 1)
+    assert a == L.lib().flair_unet_workspace_bytes(m._h, 2, 64, 64, 1) > 0
+    assert L.lib().flair_unet_workspace_bytes(m._h, 2, 64, 64, 0) < a
+    assert L.lib().flair_unet_workspace_bytes(m._h, 2, 70, 64, 1) == -1
+    big = L.lib().flair_unet_workspace_bytes(m._h, 32, 512, 512, 1)
+    assert 8e9 < big < 40e9  # fits 288 GB HBM with a wide margin
+
+
+def test_bucket_ranges_and_sharding():
+    from flair_amd import bucket_ranges, shard_indices
+    sr = [(0, 16), (16, 240), (240, 1400), (1400, 8200), (8200, 21300), (21300, 24400), (24400, 24404)]
+    b = bucket_ranges(sr, min_elems=1000)
+    assert b[0][1] == 24404 and b[-1][0] == 0  # ready order: head end first, stem last
+    assert all(x[0] == y[1] for x, y in zip(b, b[1:]))  # contiguous, descending
+    assert sum(e - s for s, e in b) == 24404 and all(e - s >= 1000 for s, e in b)
+    assert bucket_ranges(sr, 0)[0] == (24400, 24404)
+    parts = [shard_indices(10, r, 4, epoch_seed=3) for r in range(4)]
+    assert all(len(p) == 3 for p in parts)  # padded to 12 by wrapping (DistributedSampler, drop_last=False)
+    assert set(sum(parts, [])) == set(range(10))
+    assert [shard_indices(10, r, 4, shuffle=False, drop_last=True) for r in range(4)] == [[0, 4], [1, 5], [2, 6], [3, 7]]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from flair_amd import allreduce_buckets, bucket_ranges, shard_indices
+    from flair_amd.head import MeanMetric, MulticlassJaccardIndex
+    sr = [(0, 8), (8, 40), (40, 100), (100, 228), (228, 300), (300, 360), (360, 364)]
+    g = torch.arange(364, dtype=torch.float32) * (rank + 1)
+    works = allreduce_buckets(g, bucket_ranges(sr, 64), async_op=True)
+    for w in works:
+        w.wait()
+    ok = torch.equal(g, torch.arange(364, dtype=torch.float32) * sum(range(1, world + 1)))
+    # metric state sync (confusion matrix sum) through the same group
+    mj = MulticlassJaccardIndex(3, average="weighted")
+    mj.confmat += torch.eye(3, dtype=torch.int64) * (rank + 1)
+    mm = MeanMetric()
+    mm.total += float(rank + 1)
+    mm.weight += 1.0
+    cm = mj.confmat.clone()
+    dist.all_reduce(cm)
+    ok = ok and int(cm[0, 0]) == 3 and abs(mm.compute().item() - 1.5) < 1e-6
+    ok = ok and len(shard_indices(7, rank, world)) == 4
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_world2_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out[0] and out[1]
