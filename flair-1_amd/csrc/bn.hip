@@ -4,6 +4,7 @@
 // Semantics follow torch.nn.BatchNorm2d(eps=1e-5, momentum=0.1) as used by smp Unet(resnet34)
 // (SURVEY.md §2.3 K5/K6): biased variance for normalisation, unbiased for running_var.
 #include "ops.h"
+#include "prof.h"
 
 namespace flair {
 
@@ -282,6 +283,7 @@ static inline int ew_blocks(long total) {
 int bn_finalize(const float* partial, int nblk, int C, long count, const float* gamma, const float* beta,
                 float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                 float* mean_out, float* invstd_out, hipStream_t s) {
+  ProfScope ps("bn_finalize", 0.0, (double)nblk * 2 * C * 4.0, s);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 32), 0, s, partial, nblk, C, (double)count, gamma,
                      beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
   FLAIR_CHECK_LAUNCH();
@@ -300,6 +302,7 @@ int bn_act(int dtype, const void* y, const float* scale, const float* shift, con
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C % ch) return -2;
   const long total = rows * (C / ch);
+  ProfScope ps("bn_act", 0.0, (double)rows * C * dtype_size(dtype) * (res ? 3 : 2), s);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)y, scale, shift,
                        (const float*)res, rscale, rshift, (float*)out, rows, C, relu);
@@ -375,18 +378,22 @@ int bn_backward(int dtype, const void* dout, const void* out, const void* y, con
   if (C % ch || C / ch > 128) return -2;
   const int nblk = bn_bwd_blocks(rows);
   const long rpb = (rows + nblk - 1) / nblk;
+  ProfScope* ps1 = new ProfScope("bn_bwd_reduce", 0.0, (double)rows * C * dtype_size(dtype) * (out ? 3 : 2), s);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, s, (const float*)dout, (const float*)out,
                        (const float*)y, mean, invstd, partial, rows, C, rpb);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)dout,
                        (const bf16_t*)out, (const bf16_t*)y, mean, invstd, partial, rows, C, rpb);
+  delete ps1;
   FLAIR_CHECK_LAUNCH();
   float *k1 = coef, *k2 = coef + C, *k3 = coef + 2 * C;
+  ProfScope ps3("bn_bwd_finalize", 0.0, (double)nblk * 2 * C * 4.0, s);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 32), 0, s, partial, nblk, C, (double)rows, gamma,
                      invstd, dgamma, dbeta, accumulate_param, k1, k2, k3);
   FLAIR_CHECK_LAUNCH();
   const long total = rows * (C / ch);
+  ProfScope ps2("bn_bwd_apply", 0.0, (double)rows * C * dtype_size(dtype) * ((out ? 3 : 2) + 1 + (dres ? 1 : 0)), s);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)dout,
                        (const float*)out, (const float*)y, mean, invstd, k1, k2, k3, (float*)dy, (float*)dres,

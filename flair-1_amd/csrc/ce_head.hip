@@ -7,6 +7,7 @@
 // HBM-bound: reads C floats per pixel once (coalesced across pixels), integer histogram in LDS,
 // one 64-bit integer atomic per (block, cell); loss reduced through deterministic partials.
 #include "ops.h"
+#include "prof.h"
 
 namespace flair {
 
@@ -189,15 +190,19 @@ int ce_head(const CeArgs& a, hipStream_t s) {
   float* den_partial = a.workspace + (npix + 3) / 4;
   float* loss_partial = den_partial + CE_MAX_BLOCKS;
   float* den = loss_partial + CE_MAX_BLOCKS;
+  ProfScope* p1 = new ProfScope("ce_labels", 0.0, (double)npix * (a.label_kind == 3 ? 4.0 * a.C : 1.0), s);
   hipLaunchKernelGGL(ce_labels_kernel, dim3(nb), dim3(256), 0, s, a.labels, a.label_kind, a.weight, a.C, HW, npix, lab8,
                      a.targets_i32, den_partial);
   FLAIR_CHECK_LAUNCH();
+  delete p1;
   hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, s, den_partial, nb, den, (const float*)nullptr);
   FLAIR_CHECK_LAUNCH();
+  ProfScope* p2 = new ProfScope("ce_main", 0.0, (double)npix * (4.0 * a.C * (1 + (a.dlogits_nchw ? 1 : 0)) + 2 + (a.dlogits_nhwc ? a.dlogits_ld * dtype_size(a.dlogits_dtype) : 0)), s);
   hipLaunchKernelGGL(ce_main_kernel, dim3(nb), dim3(256), 0, s, a.logits, lab8, a.weight, den, a.C, HW, npix,
                      loss_partial, a.dlogits_nchw, a.dlogits_nhwc, a.dlogits_dtype, a.dlogits_ld, a.preds_u8,
                      a.preds_i64, a.confmat);
   FLAIR_CHECK_LAUNCH();
+  delete p2;
   hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, s, loss_partial, nb, a.loss, den);
   FLAIR_CHECK_LAUNCH();
   return 0;
@@ -238,6 +243,7 @@ int softmax_argmax(const float* logits, int B, int C, int H, int W, unsigned cha
                    float* maxprob, hipStream_t s) {
   if (C > MAXC || C < 1) return -2;
   const long HW = (long)H * W, npix = HW * B;
+  ProfScope ps("softmax_argmax", 0.0, (double)npix * (4.0 * C + 1), s);
   hipLaunchKernelGGL(softmax_argmax_kernel, dim3(ce_blocks(npix)), dim3(256), 0, s, logits, C, HW, npix, preds_u8,
                      preds_i64, maxprob);
   FLAIR_CHECK_LAUNCH();

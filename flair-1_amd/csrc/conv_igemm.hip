@@ -10,20 +10,22 @@
 // Epilogue: accumulators -> LDS -> 16-byte coalesced NHWC stores (or fp32 NCHW for the head),
 // plus per-row-block partial BatchNorm sums (deterministic: no atomics).
 #include "common.h"
+#include "prof.h"
 
 namespace flair {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // first-class 16-byte vector (SSA-friendly, unlike HIP's uint4 struct)
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&a),
-                                                *reinterpret_cast<const bf16x8_t*>(&b), c, 0, 0, 0);
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
 };
 template <> struct Mma<float> {
-  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4_t& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         iw0[i] = wo * a.out_mul - a.pad;
         nb[i] = n;
       } else {
-        ih0[i] = -(1 << 28); iw0[i] = -(1 << 28); nb[i] = 0;
+        ih0[i] = -(1 << 28); iw0[i] = -(1 << 28); nb[i] = 0;  // fails every bounds check -> zero rows
       }
     }
   }
@@ -95,42 +97,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int Hs0 = a.up0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.up0 ? (a.Win >> 1) : a.Win;
   const int nsteps = a.Kpad / BKE;
 
-  uint4 areg[AROWS], breg[BROWS];
+  // Branch-free gather: every lane always issues its 16-byte load (out-of-image taps read the tensor base
+  // and are zeroed by a select when the registers are written to LDS), so all loads of a K step are in
+  // flight together behind one s_waitcnt instead of one memory round trip per row.
+  u32x4 areg[AROWS], breg[BROWS];
+  bool aok[AROWS];
   auto load_regs = [&](int step) {
+    const bool use0 = kc < a.C0;
+    const T* __restrict__ base = use0 ? src0 : src1;
+    const int Hs = use0 ? Hs0 : a.Hin, Ws = use0 ? Ws0 : a.Win, Cs = use0 ? a.C0 : a.C1;
+    const int sh = (use0 && a.up0) ? 1 : 0;
+    const int coff = use0 ? kc : kc - a.C0;
+    const bool tap_ok = kr < a.R;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       int hn = ih0[i] + kr, wq = iw0[i] + ks;
-      bool ok = kr < a.R;
+      bool ok = tap_ok;
       if (a.in_div == 2) {
         ok = ok && (((hn | wq) & 1) == 0);
         hn >>= 1; wq >>= 1;
       }
       ok = ok && ((unsigned)hn < (unsigned)a.Hin) && ((unsigned)wq < (unsigned)a.Win);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        const T* p;
-        if (kc < a.C0) {
-          int hs = a.up0 ? (hn >> 1) : hn, ws = a.up0 ? (wq >> 1) : wq;
-          p = src0 + (((long)nb[i] * Hs0 + hs) * Ws0 + ws) * a.C0 + kc;
-        } else {
-          p = src1 + (((long)nb[i] * a.Hin + hn) * a.Win + wq) * a.C1 + (kc - a.C0);
-        }
-        v = *reinterpret_cast<const uint4*>(p);
-        if (a.in_scale) {
-          float f[CH];
-          chunk_to_f<T>(v, f);
-#pragma unroll
-          for (int e = 0; e < CH; ++e) f[e] = fmaxf(fmaf(f[e], a.in_scale[kc + e], a.in_shift[kc + e]), 0.f);
-          v = f_to_chunk<T>(f);
-        }
-      }
-      areg[i] = v;
+      const unsigned off = ok ? (unsigned)(((nb[i] * Hs + (hn >> sh)) * Ws + (wq >> sh)) * Cs + coff) : 0u;
+      areg[i] = *reinterpret_cast<const u32x4*>(base + off);
+      aok[i] = ok;
     }
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
-      int row = rb + 32 * j;
-      if (row < BN)
-        breg[j] = *reinterpret_cast<const uint4*>(wp + (long)(n0 + row) * a.Kpad + (long)step * BKE + cc * CH);
+      const int row = (BN >= 32) ? rb + 32 * j : (rb & (BN - 1));
+      breg[j] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + row) * a.Kpad + (long)step * BKE + cc * CH);
     }
     // advance the K decode by one step
     kc += BKE;
@@ -143,11 +138,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     unsigned char* sA = smem + stage * Cfg::STAGE;
     unsigned char* sB = sA + BM * 128;
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) *reinterpret_cast<uint4*>(sA + lds_off(rb + 32 * i, cc)) = areg[i];
+    for (int i = 0; i < AROWS; ++i) {
+      const unsigned m = aok[i] ? 0xffffffffu : 0u;
+      *reinterpret_cast<u32x4*>(sA + lds_off(rb + 32 * i, cc)) = areg[i] & m;
+    }
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
-      int row = rb + 32 * j;
-      if (row < BN) *reinterpret_cast<uint4*>(sB + lds_off(row, cc)) = breg[j];
+      if constexpr (BN >= 32) {
+        *reinterpret_cast<u32x4*>(sB + lds_off(rb + 32 * j, cc)) = breg[j];
+      } else {
+        if (rb < BN) *reinterpret_cast<u32x4*>(sB + lds_off(rb, cc)) = breg[j];
+      }
     }
   };
 
@@ -163,25 +164,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int lr = lane & 15, lq = lane >> 4;
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
-    const bool more = step + 1 < nsteps;
-    if (more) load_regs(step + 1);
+    // unconditional prefetch (the last iteration re-reads its own weight step and taps beyond R, all
+    // zero-masked, into the stage nobody reads): keeps the loop body straight-line for the compiler
+    load_regs(step + 1 < nsteps ? step + 1 : step);
     const unsigned char* sA = smem + cur * Cfg::STAGE;
     const unsigned char* sB = sA + BM * 128;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      uint4 af[TM], bfr[TN];
+      u32x4 af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const uint4*>(sA + lds_off(wm * WM + i * 16 + lr, lq + 4 * h));
+        af[i] = *reinterpret_cast<const u32x4*>(sA + lds_off(wm * WM + i * 16 + lr, lq + 4 * h));
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bfr[j] = *reinterpret_cast<const uint4*>(sB + lds_off(wn * WN + j * 16 + lr, lq + 4 * h));
+        bfr[j] = *reinterpret_cast<const u32x4*>(sB + lds_off(wn * WN + j * 16 + lr, lq + 4 * h));
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
     }
-    if (more) write_lds(cur ^ 1);
+    write_lds(cur ^ 1);
     __syncthreads();
   }
 
@@ -277,7 +279,18 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::SMEM, s, a);
+  {
+    // algorithmic work: 2*M*Cout*K real MACs (a data gradient with in_div = 2 only touches 1/4 of the taps)
+    const double flops = 2.0 * (double)M * a.Cout * a.Kg / (a.in_div * a.in_div);
+    const double bytes = ((double)a.N * a.Hin * a.Win / (a.in_div * a.in_div) / (a.up0 ? 4 : 1) * a.C0 +
+                          (double)a.N * a.Hin * a.Win * a.C1 + (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) +
+                         (double)a.Cout * a.Kg * sizeof(T);
+    static const char* names[2][4] = {{"conv_igemm_f32_128x128", "conv_igemm_f32_128x64", "conv_igemm_f32_256x32", "conv_igemm_f32_256x16"},
+                                      {"conv_igemm_bf16_128x128", "conv_igemm_bf16_128x64", "conv_igemm_bf16_256x32", "conv_igemm_bf16_256x16"}};
+    const int ci = BN == 128 ? 0 : BN == 64 ? 1 : BN == 32 ? 2 : 3;
+    ProfScope ps(names[sizeof(T) == 2][ci], flops, bytes, s);
+    hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::SMEM, s, a);
+  }
   FLAIR_CHECK_LAUNCH();
   return 0;
 }

@@ -3,6 +3,7 @@
 // weight packing (PyTorch OIHW fp32 master -> [Cout][(r,s),c] T, optionally flipped/transposed for
 // the data gradient), plain SGD (src/flair/tasks_utils.py:95) and small utilities.
 #include "ops.h"
+#include "prof.h"
 
 namespace flair {
 
@@ -246,6 +247,7 @@ int maxpool3x3s2_fwd(int dtype, const void* in, void* out, unsigned char* idx, i
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C % ch || (H & 1) || (W & 1)) return -2;
   const long total = (long)N * (H / 2) * (W / 2) * (C / ch);
+  ProfScope ps("maxpool_fwd", 0.0, (double)N * H * W * C * dtype_size(dtype) * 1.25 + (double)N * H * W * C / 4, s);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, (float*)out, idx, N, H, W, C);
   else
@@ -259,6 +261,7 @@ int maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, void
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C % ch || (H & 1) || (W & 1)) return -2;
   const long total = (long)N * H * W * (C / ch);
+  ProfScope ps("maxpool_bwd", 0.0, (double)N * H * W * C * (dtype_size(dtype) * (1.25 + accumulate) + 0.25), s);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)dout, idx, (float*)din, accumulate, N, H, W, C);
   else
@@ -272,6 +275,7 @@ int upcat_bwd(int dtype, const void* dcat, void* dx0, int dx0_accumulate, void* 
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C0 % ch || C1 % ch || (H & 1) || (W & 1)) return -2;
   const long total = (long)N * (H / 2) * (W / 2) * (C0 / ch) + (long)N * H * W * (C1 / ch);
+  ProfScope ps("upcat_bwd", 0.0, ((double)N * H * W * (C0 + C1) + (double)N * H * W * (C0 / 4.0 * (1 + dx0_accumulate) + C1 * (1 + dskip_accumulate))) * dtype_size(dtype), s);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(upcat_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)dcat, (float*)dx0, dx0_accumulate, (float*)dskip, dskip_accumulate, N, H, W, C0, C1);
   else
@@ -284,6 +288,7 @@ int nchw_f32_to_nhwc(int dtype, const float* in, void* out, int N, int C, int H,
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (Cp % ch || Cp < C) return -2;
   const long total = (long)N * H * W;
+  ProfScope ps("nchw_to_nhwc", 0.0, (double)N * H * W * (C * 4.0 + Cp * dtype_size(dtype)), s);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, in, (float*)out, N, C, (long)H * W, Cp);
   else
@@ -299,6 +304,7 @@ int nhwc_to_nchw_f32(int dtype, const void* in, float* out, int N, int C, int H,
   const long total = (long)N * H * W;
   float* dst = accumulate_into ? accumulate_into : out;
   const int acc = accumulate_into ? 1 : 0;
+  ProfScope ps("nhwc_to_nchw", 0.0, (double)N * H * W * (C * 4.0 + Cp * dtype_size(dtype)), s);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, dst, N, C, (long)H * W, Cp, acc);
   else
@@ -310,6 +316,7 @@ int nhwc_to_nchw_f32(int dtype, const void* in, float* out, int N, int C, int H,
 int pack_weight(int dtype, const float* w_oihw, void* dst, int Cout, int Cin, int R, int S, int Cin_p, int rows_pad,
                 int Kpad, int transpose_flip, hipStream_t s) {
   const long total = (long)rows_pad * Kpad;
+  ProfScope ps("pack_weight", 0.0, (double)Cout * Cin * R * S * 4.0 + (double)total * dtype_size(dtype), s);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, w_oihw, (float*)dst, Cout, Cin, R, S, Cin_p, rows_pad, Kpad, transpose_flip);
   else
@@ -320,6 +327,7 @@ int pack_weight(int dtype, const float* w_oihw, void* dst, int Cout, int Cin, in
 
 int sgd_step(float* params, const float* grads, long n, float lr, hipStream_t s) {
   if (((uintptr_t)params | (uintptr_t)grads) & 15) return -2;
+  ProfScope ps("sgd", 0.0, (double)n * 12.0, s);
   hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, s, params, grads, n, lr);
   FLAIR_CHECK_LAUNCH();
   return 0;

@@ -7,11 +7,14 @@
 // slabs are summed in a fixed order by wgrad_reduce_kernel (deterministic, no float atomics),
 // which also permutes [k][(r,s),c] -> PyTorch OIHW.
 #include "common.h"
+#include "prof.h"
 
 namespace flair {
 
 // LDS panel = [rows = pixels][128 bytes of channels]; XOR on byte bits 5,6 keeps the 8 rows a
 // half-wave touches in one transposed read on distinct bank groups.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // first-class 16-byte vector (keeps staging arrays in registers)
+
 __device__ __forceinline__ int wg_off(int row, int byte_in_row) {
   const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
   return row * 128 + (byte_in_row ^ (f << 5));
@@ -33,35 +36,34 @@ template <typename T> struct WgFrag;
 template <> struct WgFrag<bf16_t> {
   static constexpr int KSTEP = 32;  // pixels per MFMA
   // fragment for a 16-column group starting at byte cb of the panel, pixels kb..kb+31
-  __device__ static __forceinline__ uint4 load(const unsigned char* panel, int kb, int cb, int lane) {
+  __device__ static __forceinline__ u32x4 load(const unsigned char* panel, int kb, int cb, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     typedef __attribute__((address_space(3))) s16x4_t* lds_p;
     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(panel + wg_off(kb + 8 * g + q, cb + 8 * p)));
     s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(panel + wg_off(kb + 8 * g + 4 + q, cb + 8 * p)));
-    uint4 r;
+    u32x4 r;
     r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
     r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
     r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
     r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
     return r;
   }
-  __device__ static __forceinline__ void mma(const uint4& a, const uint4& b, f32x4_t& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&a),
-                                                *reinterpret_cast<const bf16x8_t*>(&b), c, 0, 0, 0);
+  __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
 };
 template <> struct WgFrag<float> {
   static constexpr int KSTEP = 16;  // 4 MFMAs of k=4
-  __device__ static __forceinline__ uint4 load(const unsigned char* panel, int kb, int cb, int lane) {
+  __device__ static __forceinline__ u32x4 load(const unsigned char* panel, int kb, int cb, int lane) {
     const int g = lane >> 4, i = lane & 15;
-    uint4 r;
+    u32x4 r;
     r.x = *reinterpret_cast<const unsigned*>(panel + wg_off(kb + g, cb + 4 * i));
     r.y = *reinterpret_cast<const unsigned*>(panel + wg_off(kb + 4 + g, cb + 4 * i));
     r.z = *reinterpret_cast<const unsigned*>(panel + wg_off(kb + 8 + g, cb + 4 * i));
     r.w = *reinterpret_cast<const unsigned*>(panel + wg_off(kb + 12 + g, cb + 4 * i));
     return r;
   }
-  __device__ static __forceinline__ void mma(const uint4& a, const uint4& b, f32x4_t& c) {
+  __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4_t& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
@@ -112,41 +114,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs ka) {
     cs[pn] = tap - cr[pn] * a.S;
   }
 
-  uint4 ra[PA][2], rbv[PB][2];
+  // Branch-free staging loads (invalid lanes read the tensor base and are masked to zero when written to
+  // LDS) so that every load of a stage is in flight behind a single wait.
+  u32x4 ra[PA][2], rbv[PB][2];
+  unsigned ma[PA][2], mb[PB][2];
   auto load_regs = [&](long p0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const long p = p0 + rb + 32 * i;
       const bool pok = p < pend;
-      int n = 0, ho = 0, wo = 0;
-      if (pok) {
-        n = (int)(p / HW);
-        int rem = (int)(p - (long)n * HW);
-        ho = rem / a.Wout;
-        wo = rem - ho * a.Wout;
-      }
+      const long pc = pok ? p : pbeg;
+      const int n = (int)(pc / HW);
+      const int rem = (int)(pc - (long)n * HW);
+      const int ho = rem / a.Wout;
+      const int wo = rem - ho * a.Wout;
 #pragma unroll
       for (int pn = 0; pn < PA; ++pn) {
         const int col = k0 + pn * PC + cc * CH;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (pok && col < a.dy_ld) v = *reinterpret_cast<const uint4*>(dy + p * a.dy_ld + col);
-        ra[pn][i] = v;
+        const bool ok = pok && col < a.dy_ld;
+        ra[pn][i] = *reinterpret_cast<const u32x4*>(dy + (ok ? pc * a.dy_ld + col : 0));
+        ma[pn][i] = ok ? 0xffffffffu : 0u;
       }
 #pragma unroll
       for (int pn = 0; pn < PB; ++pn) {
-        uint4 v = make_uint4(0, 0, 0, 0);
         const int hn = ho * a.stride - a.pad + cr[pn], wq = wo * a.stride - a.pad + cs[pn];
-        if (pok && cok[pn] && (unsigned)hn < (unsigned)a.Hin && (unsigned)wq < (unsigned)a.Win) {
-          const T* ptr;
-          if (ccn[pn] < a.C0) {
-            int hs = a.up0 ? (hn >> 1) : hn, ws = a.up0 ? (wq >> 1) : wq;
-            ptr = x0 + (((long)n * Hs0 + hs) * Ws0 + ws) * a.C0 + ccn[pn];
-          } else {
-            ptr = x1 + (((long)n * a.Hin + hn) * a.Win + wq) * a.C1 + (ccn[pn] - a.C0);
-          }
-          v = *reinterpret_cast<const uint4*>(ptr);
-        }
-        rbv[pn][i] = v;
+        const bool ok = pok && cok[pn] && (unsigned)hn < (unsigned)a.Hin && (unsigned)wq < (unsigned)a.Win;
+        const bool use0 = ccn[pn] < a.C0;
+        const T* __restrict__ base = use0 ? x0 : x1;
+        const int sh = (use0 && a.up0) ? 1 : 0;
+        const long off = use0 ? (((long)n * Hs0 + (hn >> sh)) * Ws0 + (wq >> sh)) * a.C0 + ccn[pn]
+                              : (((long)n * a.Hin + hn) * a.Win + wq) * a.C1 + (ccn[pn] - a.C0);
+        rbv[pn][i] = *reinterpret_cast<const u32x4*>(base + (ok ? off : 0));
+        mb[pn][i] = ok ? 0xffffffffu : 0u;
       }
     }
   };
@@ -156,10 +155,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs ka) {
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int pn = 0; pn < PA; ++pn)
-        *reinterpret_cast<uint4*>(base + pn * Cfg::PANEL + wg_off(rb + 32 * i, cc * 16)) = ra[pn][i];
+        *reinterpret_cast<u32x4*>(base + pn * Cfg::PANEL + wg_off(rb + 32 * i, cc * 16)) = ra[pn][i] & ma[pn][i];
 #pragma unroll
       for (int pn = 0; pn < PB; ++pn)
-        *reinterpret_cast<uint4*>(base + (PA + pn) * Cfg::PANEL + wg_off(rb + 32 * i, cc * 16)) = rbv[pn][i];
+        *reinterpret_cast<u32x4*>(base + (PA + pn) * Cfg::PANEL + wg_off(rb + 32 * i, cc * 16)) = rbv[pn][i] & mb[pn][i];
     }
   };
 
@@ -177,12 +176,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs ka) {
   __syncthreads();
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
-    const bool more = step + 1 < nsteps;
-    if (more) load_regs(pbeg + (long)(step + 1) * BP);
+    load_regs(pbeg + (long)(step + 1) * BP);  // past the end every lane is masked: straight-line loop body
     const unsigned char* base = smem + cur * Cfg::STAGE;
 #pragma unroll
     for (int kb = 0; kb < BP; kb += KSTEP) {
-      uint4 af[TM], bfr[TN];
+      u32x4 af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int col = wm * WM + i * 16;  // channel within the dY tile
@@ -198,7 +196,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs ka) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) WgFrag<T>::mma(af[i], bfr[j], acc[i][j]);
     }
-    if (more) write_lds(cur ^ 1);
+    write_lds(cur ^ 1);
     __syncthreads();
   }
   // partial slab [z][Cout_pad][Kpad]
@@ -246,7 +244,7 @@ static void wg_plan(int dtype, const WgradArgs& a, int& bmk, int& bnn, int& spli
   Cout_pad = (int)round_up(a.Cout, bmk);
   const long M = (long)a.N * a.Hout * a.Wout;
   const int tiles = (Cout_pad / bmk) * (Kpad / bnn);
-  long want = 1536 / tiles;
+  long want = (768 + tiles - 1) / tiles;  // ~3 blocks per CU in flight; every split costs a slab write + read
   if (want < 1) want = 1;
   long max_splits = (M + 64 * 8 - 1) / (64 * 8);  // at least 8 LDS stages per split
   if (max_splits < 1) max_splits = 1;
@@ -273,6 +271,10 @@ static int wg_launch(const WgKArgs& ka, int splits, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(ka.Cout_pad / BMK, ka.Kpad / BNN, splits);
+  const double M = (double)ka.a.N * ka.a.Hout * ka.a.Wout;
+  const double flops = 2.0 * M * ka.a.Cout * ka.Kg;
+  const double bytes = (M * ka.a.dy_ld + (double)ka.a.N * ka.a.Hin * ka.a.Win * (ka.a.C0 / (ka.a.up0 ? 4.0 : 1.0) + ka.a.C1)) * sizeof(T);
+  ProfScope ps(sizeof(T) == 2 ? (BMK == 128 ? "wgrad_bf16_128x128" : "wgrad_bf16_64x64") : "wgrad_f32_64x64", flops, bytes, s);
   hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::SMEM, s, ka);
   FLAIR_CHECK_LAUNCH();
   return 0;
@@ -294,6 +296,7 @@ int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
   const long total = (long)a.Cout * ka.Kg;
   int blocks = cdiv(total, 256);
   if (blocks > 4096) blocks = 4096;
+  ProfScope ps("wgrad_reduce", 0.0, ((double)splits + 1.0) * a.Cout * ka.Kg * 4.0, s);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.dw, splits, a.Cout, ka.Cout_pad,
                      ka.Kpad, Cin, a.Cin_real, a.R, a.S, a.accumulate);
   FLAIR_CHECK_LAUNCH();

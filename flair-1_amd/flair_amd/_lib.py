@@ -56,6 +56,10 @@ PROTOTYPES = {
     "flair_maxpool_backward": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "flair_nchw_to_nhwc": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "flair_nhwc_to_nchw": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "flair_profile_start": (i32, [i32]),
+    "flair_profile_stop": (i32, []),
+    "flair_profile_kernel": (i32, [i32, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]),
 }
 
 

