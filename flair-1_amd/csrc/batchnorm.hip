@@ -1,6 +1,8 @@
 // BatchNorm2d (training-mode batch statistics, eval-mode running statistics) + ReLU + residual add,
 // forward and backward, NHWC.  HBM-bound elementwise / reduction kernels: 16-byte accesses per lane,
-// two-stage deterministic reductions (per-block partial rows -> fp64 finalize), no float atomics.
+// two-stage deterministic reductions, no float atomics.
+// Partial sums are stored CHANNEL-MAJOR, partial[2][C][nblk], so the finalize kernels (one workgroup per
+// channel, fp64 accumulation) read them fully coalesced instead of walking a strided column serially.
 // Semantics follow torch.nn.BatchNorm2d(eps=1e-5, momentum=0.1) as used by smp Unet(resnet34)
 // (SURVEY.md §2.3 K5/K6): biased variance for normalisation, unbiased for running_var.
 #include "ops.h"
@@ -8,28 +10,33 @@
 
 namespace flair {
 
-// partial [nblk][2][C] -> scale/shift (+ saved mean / invstd, running-stat update)
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                   float eps, float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  __shared__ double sh[2][32][33];
-  const int cx = threadIdx.x, ry = threadIdx.y;
-  const int c = blockIdx.x * 32 + cx;
-  double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-    for (int b = ry; b < nblk; b += 32) {
-      s1 += (double)partial[((long)b * 2 + 0) * C + c];
-      s2 += (double)partial[((long)b * 2 + 1) * C + c];
-    }
-  }
-  sh[0][ry][cx] = s1;
-  sh[1][ry][cx] = s2;
+// sum of v over the 256 threads of the block (valid in every thread)
+__device__ __forceinline__ double block_sum_f64(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
-  if (ry == 0 && c < C) {
-    double a1 = 0.0, a2 = 0.0;
-    for (int r = 0; r < 32; ++r) { a1 += sh[0][r][cx]; a2 += sh[1][r][cx]; }
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// partial [2][C][nblk] -> scale/shift (+ saved mean / invstd, running-stat update); grid = C
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float momentum, float eps, float* __restrict__ scale,
+                                                          float* __restrict__ shift, float* __restrict__ mean_out,
+                                                          float* __restrict__ invstd_out) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  const float* p1 = partial + (long)c * nblk;
+  const float* p2 = partial + ((long)C + c) * nblk;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) { s1 += (double)p1[b]; s2 += (double)p2[b]; }
+  const double a1 = block_sum_f64(s1, sh);
+  const double a2 = block_sum_f64(s2, sh);
+  if (threadIdx.x == 0) {
     const double mean = a1 / count;
     double var = a2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -91,7 +98,7 @@ __global__ void bn_act_kernel(const T* __restrict__ y, const float* __restrict__
   }
 }
 
-// partial[blk][0][c] = sum dz ; partial[blk][1][c] = sum dz * xhat ; dz = dout * (out > 0)
+// partial[0][c][blk] = sum dz ; partial[1][c][blk] = sum dz * xhat ; dz = dout * (out > 0)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
@@ -109,35 +116,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
   for (int e = 0; e < CH; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
   float mu[CH], is[CH];
-  if (rl < rl_n) {
 #pragma unroll
-    for (int e = 0; e < CH; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > rows) r1 = rows;
-    for (long r = r0 + rl; r < r1; r += rl_n) {
-      const long off = r * C + c;
-      float d[CH], yy[CH];
-      chunk_to_f<T>(*reinterpret_cast<const uint4*>(dout + off), d);
-      chunk_to_f<T>(*reinterpret_cast<const uint4*>(y + off), yy);
-      if (out) {
-        float o[CH];
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(out + off), o);
+  for (int e = 0; e < CH; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (long r = r0 + rl; r < r1; r += rl_n) {
+    const long off = r * C + c;
+    float d[CH], yy[CH];
+    chunk_to_f<T>(*reinterpret_cast<const uint4*>(dout + off), d);
+    chunk_to_f<T>(*reinterpret_cast<const uint4*>(y + off), yy);
+    if (out) {
+      float o[CH];
+      chunk_to_f<T>(*reinterpret_cast<const uint4*>(out + off), o);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
-      }
+      for (int e = 0; e < CH; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+    }
 #pragma unroll
-      for (int e = 0; e < CH; ++e) {
-        s1[e] += d[e];
-        s2[e] += d[e] * ((yy[e] - mu[e]) * is[e]);
-      }
+    for (int e = 0; e < CH; ++e) {
+      s1[e] += d[e];
+      s2[e] += d[e] * ((yy[e] - mu[e]) * is[e]);
     }
   }
 #pragma unroll
   for (int e = 0; e < CH; ++e) { sh[(t * 2 + 0) * CH + e] = s1[e]; sh[(t * 2 + 1) * CH + e] = s2[e]; }
   __syncthreads();
-  // tree over row lanes (rl_n is a power of two because C and CH are)
-  for (int stride = rl_n >> 1; stride > 0; stride >>= 1) {
+  for (int stride = rl_n >> 1; stride > 0; stride >>= 1) {  // rl_n is a power of two
     if (rl < stride) {
       const int o = (rl + stride) * cpr + cx;
 #pragma unroll
@@ -146,34 +150,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     __syncthreads();
   }
   if (rl == 0) {
+    const long nblk = gridDim.x;
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
-      partial[((long)blockIdx.x * 2 + 0) * C + c + e] = sh[(t * 2 + 0) * CH + e];
-      partial[((long)blockIdx.x * 2 + 1) * C + c + e] = sh[(t * 2 + 1) * CH + e];
+      partial[(long)(c + e) * nblk + blockIdx.x] = sh[(t * 2 + 0) * CH + e];
+      partial[((long)C + c + e) * nblk + blockIdx.x] = sh[(t * 2 + 1) * CH + e];
     }
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                       float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
-  __shared__ double sh[2][32][33];
-  const int cx = threadIdx.x, ry = threadIdx.y;
-  const int c = blockIdx.x * 32 + cx;
+// grid = C
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                              float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  const float* p1 = partial + (long)c * nblk;
+  const float* p2 = partial + ((long)C + c) * nblk;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-    for (int b = ry; b < nblk; b += 32) {
-      s1 += (double)partial[((long)b * 2 + 0) * C + c];
-      s2 += (double)partial[((long)b * 2 + 1) * C + c];
-    }
-  }
-  sh[0][ry][cx] = s1;
-  sh[1][ry][cx] = s2;
-  __syncthreads();
-  if (ry == 0 && c < C) {
-    double a1 = 0.0, a2 = 0.0;
-    for (int r = 0; r < 32; ++r) { a1 += sh[0][r][cx]; a2 += sh[1][r][cx]; }
+  for (int b = threadIdx.x; b < nblk; b += 256) { s1 += (double)p1[b]; s2 += (double)p2[b]; }
+  const double a1 = block_sum_f64(s1, sh);
+  const double a2 = block_sum_f64(s2, sh);
+  if (threadIdx.x == 0) {
     if (dgamma) {
       dgamma[c] = accumulate ? dgamma[c] + (float)a2 : (float)a2;
       dbeta[c] = accumulate ? dbeta[c] + (float)a1 : (float)a1;
@@ -227,7 +226,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
   }
 }
 
-// column sums of x[rows][ld] (first C columns) -> out[C]; two-stage, deterministic (head bias gradient)
+// column sums of x[rows][ld] -> partial[ld][nblk]; two-stage, deterministic (head bias gradient)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const T* __restrict__ x, long rows, int ld,
                                                             float* __restrict__ partial, long rows_per_block) {
@@ -260,17 +259,18 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const T* __restrict_
   }
   if (rl == 0) {
 #pragma unroll
-    for (int e = 0; e < CH; ++e) partial[(long)blockIdx.x * ld + cx * CH + e] = sh[t * CH + e];
+    for (int e = 0; e < CH; ++e) partial[(long)(cx * CH + e) * gridDim.x + blockIdx.x] = sh[t * CH + e];
   }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int ld, int C, float* __restrict__ out) {
-  const int c = threadIdx.x;
-  if (c < C) {
-    double a = 0.0;
-    for (int b = 0; b < nblk; ++b) a += (double)partial[(long)b * ld + c];
-    out[c] = (float)a;
-  }
+// out[c] = sum_b partial[c][b]; grid = number of columns
+__global__ __launch_bounds__(256) void partial_rows_sum_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out) {
+  __shared__ double sh[4];
+  const float* p = partial + (long)blockIdx.x * nblk;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += (double)p[b];
+  const double a = block_sum_f64(s, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)a;
 }
 
 static inline int ew_blocks(long total) {
@@ -284,8 +284,8 @@ int bn_finalize(const float* partial, int nblk, int C, long count, const float* 
                 float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                 float* mean_out, float* invstd_out, hipStream_t s) {
   ProfScope ps("bn_finalize", 0.0, (double)nblk * 2 * C * 4.0, s);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 32), 0, s, partial, nblk, C, (double)count, gamma,
-                     beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, partial, nblk, C, (double)count, gamma, beta,
+                     running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }
@@ -320,22 +320,13 @@ int bn_bwd_blocks(long rows) {
   return (int)b;
 }
 
-__global__ void partial_rows_sum_kernel(const float* __restrict__ partial, int nblk, int ld, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < ld) {
-    double a = 0.0;
-    for (int b = 0; b < nblk; ++b) a += (double)partial[(long)b * ld + c];
-    out[c] = (float)a;
-  }
-}
-
-int partial_rows_sum(const float* partial, int nblk, int ld, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(partial_rows_sum_kernel, dim3(cdiv(ld, 256)), dim3(256), 0, s, partial, nblk, ld, out);
+int partial_rows_sum(const float* partial, int nblk, int ncols, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(partial_rows_sum_kernel, dim3(ncols), dim3(256), 0, s, partial, nblk, out);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }
 
-// per-block partial (sum y, sum y^2) of a standalone tensor: [bn_bwd_blocks(rows)][2][C]
+// per-block partial (sum y, sum y^2) of a standalone tensor: [2][C][bn_bwd_blocks(rows)]
 // zeros_ones: scratch of 2*C floats (filled here with mean = 0, invstd = 1)
 int bn_stats_partial(int dtype, const void* y, long rows, int C, float* partial, float* zeros_ones, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
@@ -358,7 +349,7 @@ int bn_stats_partial(int dtype, const void* y, long rows, int C, float* partial,
 
 int colsum(int dtype, const void* x, long rows, int ld, int C, float* partial, float* out, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
-  if (ld % ch || ld / ch > 256 || C > 64) return -2;
+  if (ld % ch || ld / ch > 256 || C > ld) return -2;
   const int nblk = bn_bwd_blocks(rows);
   const long rpb = (rows + nblk - 1) / nblk;
   if (dtype == DT_F32)
@@ -366,9 +357,7 @@ int colsum(int dtype, const void* x, long rows, int ld, int C, float* partial, f
   else
     hipLaunchKernelGGL(colsum_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, rows, ld, partial, rpb);
   FLAIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nblk, ld, C, out);
-  FLAIR_CHECK_LAUNCH();
-  return 0;
+  return partial_rows_sum(partial, nblk, C, out, s);
 }
 
 int bn_backward(int dtype, const void* dout, const void* out, const void* y, const float* mean, const float* invstd,
@@ -378,19 +367,22 @@ int bn_backward(int dtype, const void* dout, const void* out, const void* y, con
   if (C % ch || C / ch > 128) return -2;
   const int nblk = bn_bwd_blocks(rows);
   const long rpb = (rows + nblk - 1) / nblk;
-  ProfScope* ps1 = new ProfScope("bn_bwd_reduce", 0.0, (double)rows * C * dtype_size(dtype) * (out ? 3 : 2), s);
-  if (dtype == DT_F32)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, s, (const float*)dout, (const float*)out,
-                       (const float*)y, mean, invstd, partial, rows, C, rpb);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)dout,
-                       (const bf16_t*)out, (const bf16_t*)y, mean, invstd, partial, rows, C, rpb);
-  delete ps1;
+  {
+    ProfScope ps1("bn_bwd_reduce", 0.0, (double)rows * C * dtype_size(dtype) * (out ? 3 : 2), s);
+    if (dtype == DT_F32)
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, s, (const float*)dout, (const float*)out,
+                         (const float*)y, mean, invstd, partial, rows, C, rpb);
+    else
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)dout,
+                         (const bf16_t*)out, (const bf16_t*)y, mean, invstd, partial, rows, C, rpb);
+  }
   FLAIR_CHECK_LAUNCH();
   float *k1 = coef, *k2 = coef + C, *k3 = coef + 2 * C;
-  ProfScope ps3("bn_bwd_finalize", 0.0, (double)nblk * 2 * C * 4.0, s);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(32, 32), 0, s, partial, nblk, C, (double)rows, gamma,
-                     invstd, dgamma, dbeta, accumulate_param, k1, k2, k3);
+  {
+    ProfScope ps3("bn_bwd_finalize", 0.0, (double)nblk * 2 * C * 4.0, s);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, partial, nblk, C, (double)rows, gamma, invstd,
+                       dgamma, dbeta, accumulate_param, k1, k2, k3);
+  }
   FLAIR_CHECK_LAUNCH();
   const long total = rows * (C / ch);
   ProfScope ps2("bn_bwd_apply", 0.0, (double)rows * C * dtype_size(dtype) * ((out ? 3 : 2) + 1 + (dres ? 1 : 0)), s);

@@ -88,7 +88,7 @@ struct ConvArgs {
   void* out;         // NHWC T, row stride out_ld elements (null when only out_nchw is wanted)
   int out_ld;
   float* out_nchw;   // optional fp32 NCHW [N][Cout][Hout][Wout]
-  float* stats;      // optional per-row-block partial sums [gridDim.x][2][Cout] (sum, sum of squares)
+  float* stats;      // optional per-row-block partial sums, channel-major [2][Cout][gridDim.x] (sum, sum of squares)
   int accumulate;    // out += result
   // optional fused input transform on src0/src1: x' = relu(x*scale[c] + shift[c]) (per concatenated channel)
   const float* in_scale;

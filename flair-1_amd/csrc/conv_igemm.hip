@@ -226,8 +226,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     float x1 = 0.f, x2 = 0.f;
 #pragma unroll
     for (int w = 0; w < WAVES_M; ++w) { x1 += st[(w * BN + t) * 2]; x2 += st[(w * BN + t) * 2 + 1]; }
-    a.stats[((long)blockIdx.x * 2 + 0) * a.Cout + n0 + t] = x1;
-    a.stats[((long)blockIdx.x * 2 + 1) * a.Cout + n0 + t] = x2;
+    // channel-major partials [2][Cout][gridDim.x]: the finalize kernel reads them coalesced
+    a.stats[(long)(n0 + t) * gridDim.x + blockIdx.x] = x1;
+    a.stats[((long)a.Cout + n0 + t) * gridDim.x + blockIdx.x] = x2;
   }
   if (a.out) {
     constexpr int CPR = BN / CH;

@@ -205,6 +205,44 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
+// all layers of the network in ONE launch (blockIdx.y = layer): the per-layer table travels as a kernel argument
+template <typename T>
+__global__ void pack_weights_all_kernel(const float* __restrict__ params, unsigned char* __restrict__ base, const PackTable tb) {
+  const PackDesc d = tb.d[blockIdx.y];
+  const float* __restrict__ w = params + d.w_off;
+  T* __restrict__ dst = reinterpret_cast<T*>(base + d.dst_off);
+  const long total = (long)d.rows_pad * d.Kpad;
+  const int RS = d.R * d.S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / d.Kpad), kk = (int)(i - (long)row * d.Kpad);
+    const int tap = kk / d.Cin_p, c = kk - tap * d.Cin_p;
+    float v = 0.f;
+    if (tap < RS) {
+      const int r = tap / d.S, q = tap - r * d.S;
+      if (!d.tf) {
+        if (row < d.Cout && c < d.Cin) v = w[(((long)row * d.Cin + c) * d.R + r) * d.S + q];
+      } else {
+        if (row < d.Cin && c < d.Cout) v = w[(((long)c * d.Cin + row) * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - q)];
+      }
+    }
+    dst[i] = Elem<T>::from_f(v);
+  }
+}
+
+int pack_weights_all(int dtype, const float* params, void* base, const PackTable& tb, hipStream_t s) {
+  if (tb.n < 1 || tb.n > PackTable::MAX) return -2;
+  double bytes = 0;
+  for (int i = 0; i < tb.n; ++i) bytes += (double)tb.d[i].Cout * tb.d[i].Cin * tb.d[i].R * tb.d[i].S * 4.0 + (double)tb.d[i].rows_pad * tb.d[i].Kpad * dtype_size(dtype);
+  ProfScope ps("pack_weights_all", 0.0, bytes, s);
+  dim3 grid(64, tb.n);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(pack_weights_all_kernel<float>, grid, dim3(256), 0, s, params, (unsigned char*)base, tb);
+  else
+    hipLaunchKernelGGL(pack_weights_all_kernel<bf16_t>, grid, dim3(256), 0, s, params, (unsigned char*)base, tb);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, long n, float lr) {
   const long n4 = n / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {

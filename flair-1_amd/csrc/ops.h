@@ -17,7 +17,7 @@ int bn_backward(int dtype, const void* dout, const void* out, const void* y, con
                 const float* gamma, long rows, int C, float* partial, float* coef, float* dgamma, float* dbeta,
                 int accumulate_param, void* dy, void* dres, int dres_accumulate, hipStream_t s);
 
-int partial_rows_sum(const float* partial, int nblk, int ld, float* out, hipStream_t s);
+int partial_rows_sum(const float* partial, int nblk, int ncols, float* out, hipStream_t s);
 int bn_stats_partial(int dtype, const void* y, long rows, int C, float* partial, float* zeros_ones, hipStream_t s);
 int colsum(int dtype, const void* x, long rows, int ld, int C, float* partial, float* out, hipStream_t s);
 
@@ -32,6 +32,17 @@ int nhwc_to_nchw_f32(int dtype, const void* in, float* out, int N, int C, int H,
                      hipStream_t s);
 int pack_weight(int dtype, const float* w_oihw, void* dst, int Cout, int Cin, int R, int S, int Cin_p, int rows_pad,
                 int Kpad, int transpose_flip, hipStream_t s);
+struct PackDesc {
+  long w_off;      // float offset of the OIHW master in the flat parameter buffer
+  size_t dst_off;  // byte offset of the packed copy from the arena base
+  int Cout, Cin, R, S, Cin_p, rows_pad, Kpad, tf;
+};
+struct PackTable {
+  static constexpr int MAX = 48;
+  int n;
+  PackDesc d[MAX];
+};
+int pack_weights_all(int dtype, const float* params, void* base, const PackTable& tb, hipStream_t s);
 int sgd_step(float* params, const float* grads, long n, float lr, hipStream_t s);
 int add_rowvec_nchw(float* x, const float* v, int N, int C, int H, int W, hipStream_t s);
 int ew_add(int dtype, void* dst, const void* src, long n, hipStream_t s);

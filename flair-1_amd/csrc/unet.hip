@@ -150,18 +150,30 @@ void UNet::begin(void* ws, size_t ws_bytes, hipStream_t s, bool dry) {
   }
 }
 
+// fp32 OIHW masters -> packed T copies, all 47 convolutions in one launch
 void UNet::pack_forward_weights() {
-  for (auto& c : convs)
-    RUN(pack_weight(dtype, params_ + c.w_off, base_ + c.wf, c.Cout, c.Cin, c.R, c.S, c.Cin_p, c.rows_f, c.Kpad, 0, s_));
+  PackTable tb;
+  tb.n = 0;
+  for (auto& c : convs) {
+    PackDesc& d = tb.d[tb.n++];
+    d.w_off = c.w_off; d.dst_off = c.wf; d.Cout = c.Cout; d.Cin = c.Cin; d.R = c.R; d.S = c.S;
+    d.Cin_p = c.Cin_p; d.rows_pad = c.rows_f; d.Kpad = c.Kpad; d.tf = 0;
+  }
+  RUN(pack_weights_all(dtype, params_, base_, tb, s_));
 }
 
 void UNet::pack_dgrad_weights() {
   if (packed_d_) return;
   packed_d_ = true;
+  PackTable tb;
+  tb.n = 0;
   for (size_t i = 1; i < convs.size(); ++i) {  // the stem needs no data gradient
     auto& c = convs[i];
-    RUN(pack_weight(dtype, params_ + c.w_off, base_ + c.wd, c.Cout, c.Cin, c.R, c.S, c.Cout_p, c.rows_d, c.Kpad_d, 1, s_));
+    PackDesc& d = tb.d[tb.n++];
+    d.w_off = c.w_off; d.dst_off = c.wd; d.Cout = c.Cout; d.Cin = c.Cin; d.R = c.R; d.S = c.S;
+    d.Cin_p = c.Cout_p; d.rows_pad = c.rows_d; d.Kpad = c.Kpad_d; d.tf = 1;
   }
+  RUN(pack_weights_all(dtype, params_, base_, tb, s_));
 }
 
 void* UNet::grad_of(const Act& a, bool* accumulate) {
