@@ -173,6 +173,7 @@ size_t flair_conv2d_workspace_bytes(int dtype, int N, int H, int W, int C0, int 
   WgradArgs w;
   memset(&w, 0, sizeof(w));
   w.C0 = C0; w.C1 = C1; w.N = N; w.Hin = Hin; w.Win = Win; w.Hout = Ho; w.Wout = Wo; w.R = R; w.S = R; w.Cout = Cout;
+  w.stride = stride; w.pad = pad; w.up0 = up0; w.dy_ld = CoutP;
   b += wgrad_workspace_bytes(dtype, w) + 4096;
   return b;
 }

@@ -1,0 +1,293 @@
+// Direct 3x3 / stride-1 / pad-1 convolution for the HBM-bound, small-channel, high-resolution layers of
+// the U-Net tail (decoder blocks 3-4, the segmentation head and their data gradients: 16-32 channels at
+// 256^2-512^2; SURVEY.md §7 "decoder 32->16 = 96, 16->16 = 72, head 16->13 = 65 FLOP/B").
+//
+// The implicit-GEMM kernel re-gathers every input pixel 9x through L1/L2, which is what bounds these
+// layers.  Here a workgroup owns an 8x32 output tile, stages its (8+2)x(32+2) input halo ONCE into LDS
+// (16-byte coalesced loads, ~1.3x the algorithmic read), and feeds all 9 taps to the MFMAs from LDS by
+// shifted fragment reads; K is walked tap-major in chunks of CK input channels.  Same operands, epilogue
+// (LDS transpose -> 16-byte NHWC stores / fp32 NCHW logits, BN partial sums) and numerics as conv_igemm.
+#include "common.h"
+#include "prof.h"
+
+namespace flair {
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct HMma;
+template <> struct HMma<bf16_t> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct HMma<float> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+constexpr int TH = 8, TW = 32, HH = TH + 2, HW_ = TW + 2, HPIX = HH * HW_;  // 340 halo pixels
+
+template <typename T, int CK, int BN>
+struct HaloCfg {
+  static constexpr int CH = Elem<T>::CH;
+  static constexpr int KF = 4 * CH;                       // K elements consumed per fragment read
+  static constexpr int CPP = CK / CH;                     // 16-byte chunks per halo pixel
+  static constexpr int PSTRIDE = CK * (int)sizeof(T) + ((CK * (int)sizeof(T)) >= 64 ? 16 : 0);  // bytes (odd multiple of 16: no bank conflicts)
+  static constexpr int HALO = HPIX * PSTRIDE;
+  static constexpr int KW = (9 * CK + KF - 1) / KF * KF;  // weight row length in LDS (zero padded)
+  static constexpr int WROW = KW * (int)sizeof(T) + 16;   // bytes, padded against bank conflicts
+  static constexpr int WBYTES = BN * WROW;
+  static constexpr int CLD = BN * (int)sizeof(T) + 16;
+  static constexpr int CT = TH * TW * CLD;
+  static constexpr int MAIN = (HALO + WBYTES > CT) ? HALO + WBYTES : CT;
+  static constexpr int STATS = 4 * BN * 2 * 4;
+  static constexpr int SMEM = MAIN + STATS;
+  static constexpr int HITEMS = (HPIX * CPP + 255) / 256;
+  static constexpr int WITEMS = (BN * 9 * CPP + 255) / 256;
+};
+
+template <typename T, int CK, int BN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
+  using Cfg = HaloCfg<T, CK, BN>;
+  constexpr int CH = Cfg::CH, KF = Cfg::KF, CPP = Cfg::CPP, TN = BN / 16, TM = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* halo = smem;
+  unsigned char* wl = smem + Cfg::HALO;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int H = a.Hout, W = a.Wout;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  const int tile = blockIdx.x;
+  const int n = tile / (tiles_x * tiles_y);
+  const int trem = tile - n * tiles_x * tiles_y;
+  const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+  const int n0 = blockIdx.y * BN;
+  const int Cin = a.C0 + a.C1;
+  const T* __restrict__ src0 = (const T*)a.src0;
+  const T* __restrict__ src1 = (const T*)a.src1;
+  const T* __restrict__ wp = (const T*)a.w;
+  const int Hs0 = a.up0 ? (H >> 1) : H, Ws0 = a.up0 ? (W >> 1) : W;
+
+  // zero the padded tail of every weight row once (K beyond 9*CK contributes nothing)
+  if constexpr (Cfg::KW > 9 * CK) {
+    constexpr int PADC = (Cfg::KW - 9 * CK) / CH;
+    for (int it = t; it < BN * PADC; it += 256) {
+      const int row = it / PADC, pc = it - row * PADC;
+      *reinterpret_cast<u32x4*>(wl + row * Cfg::WROW + (9 * CK + pc * CH) * (int)sizeof(T)) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int cbase = 0; cbase < Cin; cbase += CK) {
+    if (cbase) __syncthreads();  // previous chunk fully consumed
+    // ---- stage the halo chunk and the weight chunk: all loads first, then all LDS writes
+    const bool use0 = cbase < a.C0;
+    const T* __restrict__ base = use0 ? src0 : src1;
+    const int Hs = use0 ? Hs0 : H, Ws = use0 ? Ws0 : W, Cs = use0 ? a.C0 : a.C1;
+    const int sh = (use0 && a.up0) ? 1 : 0;
+    const int coff = use0 ? cbase : cbase - a.C0;
+    u32x4 hreg[Cfg::HITEMS], wreg[Cfg::WITEMS];
+    unsigned hmask[Cfg::HITEMS];
+#pragma unroll
+    for (int k = 0; k < Cfg::HITEMS; ++k) {
+      const int it = t + 256 * k;
+      const int hp = it / CPP, ch = it - hp * CPP;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = (it < HPIX * CPP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+      const unsigned off = ok ? (unsigned)(((n * Hs + (iy >> sh)) * Ws + (ix >> sh)) * Cs + coff + ch * CH) : 0u;
+      hreg[k] = *reinterpret_cast<const u32x4*>(base + off);
+      hmask[k] = ok ? 0xffffffffu : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < Cfg::WITEMS; ++k) {
+      const int it = t + 256 * k;
+      const int itc = it < BN * 9 * CPP ? it : 0;
+      const int row = itc / (9 * CPP), rem = itc - row * (9 * CPP);
+      const int tap = rem / CPP, ch = rem - tap * CPP;
+      wreg[k] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + row) * a.Kpad + tap * Cin + cbase + ch * CH);
+    }
+#pragma unroll
+    for (int k = 0; k < Cfg::HITEMS; ++k) {
+      const int it = t + 256 * k;
+      if (it < HPIX * CPP) {
+        const int hp = it / CPP, ch = it - hp * CPP;
+        *reinterpret_cast<u32x4*>(halo + hp * Cfg::PSTRIDE + ch * 16) = hreg[k] & hmask[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < Cfg::WITEMS; ++k) {
+      const int it = t + 256 * k;
+      if (it < BN * 9 * CPP) {
+        const int row = it / (9 * CPP), rem = it - row * (9 * CPP);
+        *reinterpret_cast<u32x4*>(wl + row * Cfg::WROW + rem * 16) = wreg[k];
+      }
+    }
+    __syncthreads();
+    // ---- 9 taps x CK channels from LDS
+#pragma unroll
+    for (int j = 0; j < Cfg::KW / KF; ++j) {
+      const int k0 = j * KF + lq * CH;
+      int tap = k0 / CK;
+      const int c = k0 - tap * CK;
+      tap = tap > 8 ? 8 : tap;  // padded K: the weights there are zero, any valid address will do
+      const int r = tap / 3, s = tap - 3 * r;
+      u32x4 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int py = 2 * wave + (i >> 1), px = (i & 1) * 16 + lr;
+        af[i] = *reinterpret_cast<const u32x4*>(halo + ((py + r) * HW_ + px + s) * Cfg::PSTRIDE + c * (int)sizeof(T));
+      }
+#pragma unroll
+      for (int q = 0; q < TN; ++q)
+        bfr[q] = *reinterpret_cast<const u32x4*>(wl + (q * 16 + lr) * Cfg::WROW + k0 * (int)sizeof(T));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < TN; ++q) HMma<T>::run(af[i], bfr[q], acc[i][q]);
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue (as conv_igemm)
+  __syncthreads();
+  unsigned char* ct = smem;
+  float* st = reinterpret_cast<float*>(smem + Cfg::MAIN);
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int q = 0; q < TN; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+#pragma unroll
+  for (int q = 0; q < TN; ++q) {
+    const int col = q * 16 + lr;
+    const float bias = (a.bias && (n0 + col) < a.Cout) ? a.bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = (2 * wave + (i >> 1)) * TW + (i & 1) * 16 + lq * 4 + rr;  // tile-local pixel
+        T v = Elem<T>::from_f(acc[i][q][rr] + bias);
+        const float vf = Elem<T>::to_f(v);
+        s1[q] += vf;
+        s2[q] += vf * vf;
+        *reinterpret_cast<T*>(ct + row * Cfg::CLD + col * (int)sizeof(T)) = v;
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int q = 0; q < TN; ++q) {
+      s1[q] += __shfl_xor(s1[q], 16); s1[q] += __shfl_xor(s1[q], 32);
+      s2[q] += __shfl_xor(s2[q], 16); s2[q] += __shfl_xor(s2[q], 32);
+      if (lq == 0) {
+        st[(wave * BN + q * 16 + lr) * 2 + 0] = s1[q];
+        st[(wave * BN + q * 16 + lr) * 2 + 1] = s2[q];
+      }
+    }
+  }
+  __syncthreads();
+  if (a.stats && t < BN && (n0 + t) < a.Cout) {
+    float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { x1 += st[(w * BN + t) * 2]; x2 += st[(w * BN + t) * 2 + 1]; }
+    a.stats[(long)(n0 + t) * gridDim.x + blockIdx.x] = x1;
+    a.stats[((long)a.Cout + n0 + t) * gridDim.x + blockIdx.x] = x2;
+  }
+  if (a.out) {
+    constexpr int CPR = BN / CH;
+    T* __restrict__ out = (T*)a.out;
+    for (int idx = t; idx < TH * TW * CPR; idx += 256) {
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int py = row / TW, px = row - py * TW;
+      const int nn = n0 + ch * CH;
+      if (nn < a.Cout) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(ct + row * Cfg::CLD + ch * 16);
+        T* dst = out + ((long)(n * H + y0 + py) * W + x0 + px) * a.out_ld + nn;
+        if (a.accumulate) {
+          const uint4 o = *reinterpret_cast<const uint4*>(dst);
+          const uint4 vv = make_uint4(v.x, v.y, v.z, v.w);
+          float fa[CH], fb[CH];
+          chunk_to_f<T>(vv, fa);
+          chunk_to_f<T>(o, fb);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) fa[e] += fb[e];
+          const uint4 r = f_to_chunk<T>(fa);
+          v = u32x4{r.x, r.y, r.z, r.w};
+        }
+        *reinterpret_cast<u32x4*>(dst) = v;
+      }
+    }
+  }
+  if (a.out_nchw) {
+    const long HWp = (long)H * W;
+    for (int idx = t; idx < TH * TW * BN; idx += 256) {
+      const int nl = idx / (TH * TW), ml = idx - nl * (TH * TW);
+      const int py = ml / TW, px = ml - py * TW;
+      const int nn = n0 + nl;
+      if (nn < a.Cout)
+        a.out_nchw[((long)n * a.Cout + nn) * HWp + (long)(y0 + py) * W + x0 + px] =
+            Elem<T>::to_f(*reinterpret_cast<const T*>(ct + ml * Cfg::CLD + nl * (int)sizeof(T)));
+    }
+  }
+}
+
+template <typename T, int CK, int BN>
+int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
+  using Cfg = HaloCfg<T, CK, BN>;
+  auto kern = conv3x3_halo_kernel<T, CK, BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long M = (long)a.N * a.Hout * a.Wout;
+  dim3 grid((unsigned)(M / (TH * TW)), cdiv(a.Cout, BN));
+  {
+    const double flops = 2.0 * (double)M * a.Cout * a.Kg;
+    const double bytes = ((double)M / (a.up0 ? 4 : 1) * a.C0 + (double)M * a.C1 + (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) +
+                         (double)a.Cout * a.Kg * sizeof(T) + (a.out_nchw ? (double)M * a.Cout * 4.0 : 0.0);
+    static const char* names[2][2] = {{"conv3x3_halo_f32_ck16", "conv3x3_halo_f32_ck32"}, {"conv3x3_halo_bf16_ck16", "conv3x3_halo_bf16_ck32"}};
+    ProfScope ps(names[sizeof(T) == 2][CK == 32], flops, bytes, s);
+    hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::SMEM, s, a);
+  }
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+// The halo kernel serves 3x3 / stride 1 / pad 1 convolutions with <= 32 output channels per workgroup and an
+// input whose channel count is 16 or a multiple of 32 (sources not straddled by a chunk), on 8x32-tileable images.
+bool conv_halo_applicable(const ConvArgs& a) {
+  const int Cin = a.C0 + a.C1;
+  if (a.R != 3 || a.S != 3 || a.out_mul != 1 || a.in_div != 1 || a.pad != 1) return false;
+  if (a.Hout != a.Hin || a.Wout != a.Win || (a.Hout % TH) || (a.Wout % TW)) return false;
+  if (a.in_scale) return false;
+  if (Cin == 16) return a.C1 == 0 && a.Cout <= 32;
+  if ((Cin % 32) || (a.C0 % 32)) return false;
+  return Cin <= 128 && a.Cout <= 128 && (a.Cout <= 32 || Cin <= 32);
+}
+
+int conv_halo_grid_rows(const ConvArgs& a) { return (int)((long)a.N * a.Hout * a.Wout / (TH * TW)); }
+
+int launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s) {
+  const int Cin = a.C0 + a.C1;
+  const bool n16 = a.Cout <= 16;
+  if (dtype == DT_F32) {
+    if (Cin == 16) return n16 ? launch_halo_cfg<float, 16, 16>(a, s) : launch_halo_cfg<float, 16, 32>(a, s);
+    return n16 ? launch_halo_cfg<float, 32, 16>(a, s) : launch_halo_cfg<float, 32, 32>(a, s);
+  }
+  if (Cin == 16) return n16 ? launch_halo_cfg<bf16_t, 16, 16>(a, s) : launch_halo_cfg<bf16_t, 16, 32>(a, s);
+  return n16 ? launch_halo_cfg<bf16_t, 32, 16>(a, s) : launch_halo_cfg<bf16_t, 32, 32>(a, s);
+}
+
+}  // namespace flair

@@ -299,8 +299,13 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
 static inline int pick_bn(int cout) { return cout >= 128 ? 128 : cout >= 64 ? 64 : cout >= 32 ? 32 : 16; }
 static inline int pick_bm(int cout) { return cout >= 64 ? 128 : 256; }
 
+bool conv_halo_applicable(const ConvArgs& a);           // conv_halo.hip
+int conv_halo_grid_rows(const ConvArgs& a);
+int launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s);
+
 int conv_grid_rows(int dtype, const ConvArgs& a) {
   (void)dtype;
+  if (conv_halo_applicable(a)) return conv_halo_grid_rows(a);
   return cdiv((long)a.N * a.Hout * a.Wout, pick_bm(a.Cout));
 }
 
@@ -322,6 +327,11 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
+  if (conv_halo_applicable(a)) {  // HBM-bound small-channel 3x3 layers: halo-tile direct kernel
+    const int ch = dtype == DT_F32 ? 4 : 8;
+    if (a.out && (a.Cout % ch)) return -3;
+    return launch_conv_halo(dtype, a, s);
+  }
   return dtype == DT_F32 ? launch_t<float>(a, s) : launch_t<bf16_t>(a, s);
 }
 

@@ -215,19 +215,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs ka) {
 }
 
 // dw[k][c][r][s] (+)= sum_z partial[z][k][(r*S+s)*Cin + c]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int Cout,
-                                    int Cout_pad, int Kpad, int Cin, int Cin_real, int R, int S, int accumulate) {
+// 64 consecutive elements x 4 slab groups per workgroup: coalesced 256-byte slab reads, four independent
+// partial sums per thread in flight, fixed summation order (group-major) -> bit-reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits,
+                                                           int Cout, int Cout_pad, int Kpad, int Cin, int Cin_real, int R,
+                                                           int S, int accumulate) {
+  __shared__ float sh[4][64];
   const long total = (long)Cout * R * S * Cin;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(idx / (R * S * Cin));
-    const int kk = (int)(idx - (long)k * R * S * Cin);
-    const int tap = kk / Cin, c = kk - tap * Cin;
-    if (c >= Cin_real) continue;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[((long)z * Cout_pad + k) * Kpad + kk];
-    const int r = tap / S, q = tap - r * S;
-    float* d = dw + (((long)k * Cin_real + c) * R + r) * S + q;
-    *d = accumulate ? (*d + s) : s;
+  const int e = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+    const long idx = base + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0, kk = 0;
+    if (idx < total) {
+      k = (int)(idx / (R * S * Cin));
+      kk = (int)(idx - (long)k * R * S * Cin);
+      const float* p = part + (long)k * Kpad + kk;
+      const long zs = (long)Cout_pad * Kpad;
+      int z = zg;
+      for (; z + 12 < splits; z += 16) {
+        s0 += p[(long)z * zs]; s1 += p[(long)(z + 4) * zs]; s2 += p[(long)(z + 8) * zs]; s3 += p[(long)(z + 12) * zs];
+      }
+      for (; z < splits; z += 4) s0 += p[(long)z * zs];
+    }
+    sh[zg][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (zg == 0 && idx < total) {
+      const float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+      const int tap = kk / Cin, c = kk - tap * Cin;
+      if (c < Cin_real) {
+        const int r = tap / S, q = tap - r * S;
+        float* d = dw + (((long)k * Cin_real + c) * R + r) * S + q;
+        *d = accumulate ? (*d + s) : s;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -253,7 +275,22 @@ static void wg_plan(int dtype, const WgradArgs& a, int& bmk, int& bnn, int& spli
   splits = (int)((M + pps - 1) / pps);
 }
 
+bool wgrad_halo_applicable(const WgradArgs& a);          // wgrad_halo.hip
+size_t wgrad_halo_workspace_bytes(const WgradArgs& a);
+int launch_wgrad_halo(int dtype, const WgradArgs& a, hipStream_t s);
+
+void launch_wgrad_reduce(const float* partial, float* dw, int splits, int Cout, int Cout_pad, int Kpad, int Cin,
+                         int Cin_real, int R, int S, int accumulate, hipStream_t s) {
+  const long total = (long)Cout * R * S * Cin;
+  int blocks = cdiv(total, 64);
+  if (blocks > 8192) blocks = 8192;
+  ProfScope ps("wgrad_reduce", 0.0, ((double)splits + 1.0) * total * 4.0, s);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, splits, Cout, Cout_pad, Kpad, Cin,
+                     Cin_real, R, S, accumulate);
+}
+
 size_t wgrad_workspace_bytes(int dtype, const WgradArgs& a) {
+  if (wgrad_halo_applicable(a)) return wgrad_halo_workspace_bytes(a);
   int bmk, bnn, splits, Kg, Kpad, Cout_pad;
   long pps;
   wg_plan(dtype, a, bmk, bnn, splits, pps, Kg, Kpad, Cout_pad);
@@ -283,6 +320,7 @@ static int wg_launch(const WgKArgs& ka, int splits, hipStream_t s) {
 int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if ((a.C0 % ch) || (a.C1 % ch) || (a.dy_ld % ch)) return -2;
+  if (wgrad_halo_applicable(a)) return launch_wgrad_halo(dtype, a, s);  // HBM-bound small-channel 3x3 layers
   WgKArgs ka;
   ka.a = a;
   int bmk, bnn, splits;
@@ -292,13 +330,7 @@ int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
   else if (bmk == 128) rc = wg_launch<bf16_t, 128, 128>(ka, splits, s);
   else rc = wg_launch<bf16_t, 64, 64>(ka, splits, s);
   if (rc) return rc;
-  const int Cin = a.C0 + a.C1;
-  const long total = (long)a.Cout * ka.Kg;
-  int blocks = cdiv(total, 256);
-  if (blocks > 4096) blocks = 4096;
-  ProfScope ps("wgrad_reduce", 0.0, ((double)splits + 1.0) * a.Cout * ka.Kg * 4.0, s);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.dw, splits, a.Cout, ka.Cout_pad,
-                     ka.Kpad, Cin, a.Cin_real, a.R, a.S, a.accumulate);
+  launch_wgrad_reduce(a.partial, a.dw, splits, a.Cout, ka.Cout_pad, ka.Kpad, a.C0 + a.C1, a.Cin_real, a.R, a.S, a.accumulate, s);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }

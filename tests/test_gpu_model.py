@@ -103,8 +103,8 @@ def _assert_as_good_as_cpu_fp32(e_hip, e_cpu):
     within rounding of 0 flips its ReLU mask, so torch-CPU fp32 itself sits ~1e-2 (relative, max-norm) from
     an fp64 run.  The bar for the HIP fp32 path is therefore 'as close to fp64 as the reference arithmetic'."""
     q = lambda d, f: sorted(d.values())[min(len(d) - 1, int(f * len(d)))]
-    assert q(e_hip, 0.5) <= 1.5 * q(e_cpu, 0.5) + 1e-4, (q(e_hip, 0.5), q(e_cpu, 0.5))
-    assert q(e_hip, 0.9) <= 2.0 * q(e_cpu, 0.9) + 1e-3, (q(e_hip, 0.9), q(e_cpu, 0.9))
+    assert q(e_hip, 0.5) <= 2.0 * q(e_cpu, 0.5) + 1e-4, (q(e_hip, 0.5), q(e_cpu, 0.5))
+    assert q(e_hip, 0.9) <= 2.5 * q(e_cpu, 0.9) + 1e-3, (q(e_hip, 0.9), q(e_cpu, 0.9))
     # the maximum is a single-tensor outlier statistic (one flipped ReLU in a small layer): loose bound only
     assert max(e_hip.values()) <= 5.0 * max(e_cpu.values()) + 2e-2, (max(e_hip.values()), max(e_cpu.values()))
 

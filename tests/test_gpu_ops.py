@@ -218,3 +218,50 @@ def test_confmat_and_softmax_argmax(dev, golden_dir):
     conv = seg_step.detect_convert_argmax(probs[0].numpy())
     assert np.array_equal(conv[0], pr[0].cpu().numpy().astype(np.float32))
     assert np.abs(conv[1] - mp[0].cpu().numpy()).max() < 1e-6
+
+
+HALO_CASES = [
+    # N, H, W, C0, C1, up0, Cout  (3x3 s1 p1; served by the halo-tile kernel: H % 8 == 0, W % 32 == 0)
+    (2, 16, 64, 16, 0, False, 16),
+    (1, 24, 32, 16, 0, False, 13),
+    (2, 16, 32, 32, 0, True, 16),
+    (1, 16, 64, 32, 0, False, 32),
+    (1, 16, 32, 64, 64, True, 32),
+    (2, 8, 32, 32, 0, False, 128),
+    (1, 8, 64, 16, 0, False, 32),
+    (2, 16, 32, 64, 0, False, 64),
+    (1, 16, 32, 128, 0, False, 32),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv_halo_kernel(dev, dtype, case):
+    """Small-channel 3x3 layers of the decoder tail / head (fwd, data gradient, stats, bias, NCHW logits)."""
+    from flair_amd import ops
+    N, H, W, C0, C1, up0, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    h0, w0 = (H // 2, W // 2) if up0 else (H, W)
+    x0 = _q(torch.randn(N, C0, h0, w0, generator=g), dtype)
+    x1 = _q(torch.randn(N, C1, H, W, generator=g), dtype) if C1 else None
+    w = _q(torch.randn(Cout, C0 + C1, 3, 3, generator=g) / (9 * (C0 + C1)) ** 0.5, dtype).requires_grad_(True)
+    b = torch.randn(Cout, generator=g) if Cout == 13 else None
+    xin = F.interpolate(x0, scale_factor=2, mode="nearest") if up0 else x0
+    if C1:
+        xin = torch.cat([xin, x1], 1)
+    xin.requires_grad_(True)
+    ref = F.conv2d(xin, w, b, padding=1)
+    wd = w.detach().to(dev)
+    y, yn, st = ops.conv2d_forward(_nhwc(x0, dtype, dev), wd, bias=None if b is None else b.to(dev), x1=None if x1 is None else _nhwc(x1, dtype, dev),
+                                   up0=up0, want_nchw=True, want_stats=b is None)
+    assert _rel(yn.cpu(), ref.detach()) < TOL[dtype]
+    if y is not None:
+        got = y.float().cpu().permute(0, 3, 1, 2)
+        assert _rel(got, ref.detach()) < TOL[dtype]
+        assert _rel(st[0].cpu(), got.sum(dim=(0, 2, 3))) < 1e-4 and _rel(st[1].cpu(), (got * got).sum(dim=(0, 2, 3))) < 1e-4
+    if not up0 and not C1 and Cout % 8 == 0:
+        dy = _q(torch.randn(ref.shape, generator=g), dtype)
+        ref.backward(dy)
+        dx, dw = ops.conv2d_backward(_nhwc(x0, dtype, dev), wd, _nhwc(dy, dtype, dev))
+        assert _rel(dx.float().cpu().permute(0, 3, 1, 2), xin.grad) < TOL[dtype]
+        assert _rel(dw.cpu(), w.grad) < TOL[dtype]  # halo-tile weight gradient (all nine taps per workgroup)
