@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="rehearse the RCCL gradient exchange (events, side stream, buckets) with a single rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,7 +116,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_exchange:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     import flair_amd
@@ -125,7 +132,7 @@ def main():
                                    compute_dtype=args.dtype).to(dev).train()
     # configs/flair-1-config.yaml:50 lr 0.02 would diverge on pure-noise tiles over many steps; the step
     # arithmetic is identical for any lr, so use a small one to keep activations finite (DVFS-realistic data).
-    trainer = flair_amd.SegTrainer(model, lr=1e-3, overlap=not args.no_overlap)
+    trainer = flair_amd.SegTrainer(model, lr=1e-3, overlap=not args.no_overlap, force_exchange=args.force_exchange)
     g = torch.Generator().manual_seed(2022 + rank)  # per-rank tiles
     img = torch.randn(args.batch, 5, args.size, args.size, generator=g).to(dev)
     lab = torch.randint(0, args.classes, (args.batch, args.size, args.size), generator=g).to(torch.uint8).to(dev)
@@ -205,7 +212,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(2, args.size, args.classes, iters=6)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

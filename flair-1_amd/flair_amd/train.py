@@ -64,11 +64,14 @@ def shard_indices(n_items, rank, world, epoch_seed=0, shuffle=True, drop_last=Fa
 class SegTrainer:
     """Owns the flat gradient buffer, the fused head outputs and the RCCL exchange for one rank."""
 
-    def __init__(self, model, lr, class_weight=None, group=None, overlap=True, min_bucket_elems=1 << 18):
+    def __init__(self, model, lr, class_weight=None, group=None, overlap=True, min_bucket_elems=1 << 18,
+                 force_exchange=False):
         self.model = model
         self.lr = float(lr)
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # rehearsal switch: run the event / side-stream / RCCL exchange even with one rank (1-GPU test boxes)
+        self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
         self.overlap = overlap
         p = model.flat_parameters()
         dev = p.device
@@ -80,7 +83,7 @@ class SegTrainer:
         self._dl = None
         self._preds = None
         self._ce_ws = None
-        if self.world > 1:
+        if self.exchange:
             self.comm_stream = torch.cuda.Stream(device=dev)
             self.events = [torch.cuda.Event() for _ in range(7)]
             for e in self.events:
@@ -88,9 +91,8 @@ class SegTrainer:
             # bucket -> the stage whose completion makes it ready (its lowest stage)
             sr = model.stage_ranges()
             self._bucket_stage = [min(s for s, (b, e) in enumerate(sr) if b >= bb and e <= be and e > b) for bb, be in self.buckets]
-            if self.world > 1:
-                dist.broadcast(p, src=0, group=group)  # DDP's initial parameter broadcast
-                dist.broadcast(model.flat_buffers(), src=0, group=group)
+            dist.broadcast(p, src=0, group=group)  # DDP's initial parameter broadcast
+            dist.broadcast(model.flat_buffers(), src=0, group=group)
 
     def _buffers(self, B, H, W):
         m = self.model
@@ -115,7 +117,7 @@ class SegTrainer:
         L.check(l.flair_ce_head(L.ptr(logits), L.ptr(labels), kind, L.ptr(self.class_weight), B, m.classes, H, W,
                                 L.ptr(self.loss), None, L.ptr(self._dl), m._dt, ld, L.ptr(self._preds), None, None,
                                 L.ptr(self.confmat), L.ptr(self._ce_ws), L.stream()), "ce_head")
-        if self.world > 1 and self.overlap:
+        if self.exchange and self.overlap:
             m._c_backward(dlogits_nhwc=self._dl, grads=self.grads, stage_events=self.events)
             works = []
             with torch.cuda.stream(self.comm_stream):
@@ -126,7 +128,7 @@ class SegTrainer:
                 w.wait()
         else:
             m._c_backward(dlogits_nhwc=self._dl, grads=self.grads)
-            if self.world > 1:
+            if self.exchange:
                 allreduce_buckets(self.grads, self.buckets, self.group)
         # DDP averages: fold 1/world into the step size
         ops.sgd_step_(m._flat_p, self.grads, self.lr / self.world)
