@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             float* __restrict__ partial, long rows, int C,
-                                                            long rows_per_block) {
+                                                            long rows_per_block, const float* __restrict__ mscale,
+                                                            const float* __restrict__ mshift) {
   constexpr int CH = Elem<T>::CH;
   __shared__ float sh[256 * 2 * CH];
   const int cpr = C / CH;           // chunk columns (<= 128)
@@ -115,9 +116,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   float s1[CH], s2[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  float mu[CH], is[CH];
+  float mu[CH], is[CH], ms[CH], mh[CH];
 #pragma unroll
-  for (int e = 0; e < CH; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
+  for (int e = 0; e < CH; ++e) {
+    mu[e] = mean[c + e]; is[e] = invstd[c + e];
+    ms[e] = mscale ? mscale[c + e] : 0.f; mh[e] = mscale ? mshift[c + e] : 0.f;
+  }
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
@@ -131,6 +135,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       chunk_to_f<T>(*reinterpret_cast<const uint4*>(out + off), o);
 #pragma unroll
       for (int e = 0; e < CH; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+    } else if (mscale) {  // ReLU mask recomputed from the pre-BN tensor: out > 0  <=>  y*scale + shift > 0
+#pragma unroll
+      for (int e = 0; e < CH; ++e) d[e] = fmaf(yy[e], ms[e], mh[e]) > 0.f ? d[e] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
@@ -189,7 +196,8 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ k1, const float* __restrict__ k2,
                                     const float* __restrict__ k3, T* __restrict__ dy, T* __restrict__ dres,
-                                    int dres_accumulate, long rows, int C) {
+                                    int dres_accumulate, long rows, int C, const float* __restrict__ mscale,
+                                    const float* __restrict__ mshift) {
   constexpr int CH = Elem<T>::CH;
   const int cpr = C / CH;
   const long total = rows * cpr;
@@ -203,6 +211,9 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
       chunk_to_f<T>(*reinterpret_cast<const uint4*>(out + idx * CH), o);
 #pragma unroll
       for (int e = 0; e < CH; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+    } else if (mscale) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) d[e] = fmaf(yy[e], mscale[c + e], mshift[c + e]) > 0.f ? d[e] : 0.f;
     }
     if (dres) {
       float r[CH];
@@ -339,10 +350,10 @@ int bn_stats_partial(int dtype, const void* y, long rows, int C, float* partial,
   const long rpb = (rows + nblk - 1) / nblk;
   if (dtype == DT_F32)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, s, (const float*)y, (const float*)nullptr,
-                       (const float*)y, zeros_ones, zeros_ones + C, partial, rows, C, rpb);
+                       (const float*)y, zeros_ones, zeros_ones + C, partial, rows, C, rpb, (const float*)nullptr, (const float*)nullptr);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)y,
-                       (const bf16_t*)nullptr, (const bf16_t*)y, zeros_ones, zeros_ones + C, partial, rows, C, rpb);
+                       (const bf16_t*)nullptr, (const bf16_t*)y, zeros_ones, zeros_ones + C, partial, rows, C, rpb, (const float*)nullptr, (const float*)nullptr);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }
@@ -362,19 +373,21 @@ int colsum(int dtype, const void* x, long rows, int ld, int C, float* partial, f
 
 int bn_backward(int dtype, const void* dout, const void* out, const void* y, const float* mean, const float* invstd,
                 const float* gamma, long rows, int C, float* partial, float* coef /*3*C*/, float* dgamma, float* dbeta,
-                int accumulate_param, void* dy, void* dres, int dres_accumulate, hipStream_t s) {
+                int accumulate_param, void* dy, void* dres, int dres_accumulate, const float* mscale, const float* mshift,
+                hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C % ch || C / ch > 128) return -2;
   const int nblk = bn_bwd_blocks(rows);
   const long rpb = (rows + nblk - 1) / nblk;
   {
+    if (out) { mscale = nullptr; mshift = nullptr; }
     ProfScope ps1("bn_bwd_reduce", 0.0, (double)rows * C * dtype_size(dtype) * (out ? 3 : 2), s);
     if (dtype == DT_F32)
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, s, (const float*)dout, (const float*)out,
-                         (const float*)y, mean, invstd, partial, rows, C, rpb);
+                         (const float*)y, mean, invstd, partial, rows, C, rpb, mscale, mshift);
     else
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)dout,
-                         (const bf16_t*)out, (const bf16_t*)y, mean, invstd, partial, rows, C, rpb);
+                         (const bf16_t*)out, (const bf16_t*)y, mean, invstd, partial, rows, C, rpb, mscale, mshift);
   }
   FLAIR_CHECK_LAUNCH();
   float *k1 = coef, *k2 = coef + C, *k3 = coef + 2 * C;
@@ -389,11 +402,11 @@ int bn_backward(int dtype, const void* dout, const void* out, const void* y, con
   if (dtype == DT_F32)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)dout,
                        (const float*)out, (const float*)y, mean, invstd, k1, k2, k3, (float*)dy, (float*)dres,
-                       dres_accumulate, rows, C);
+                       dres_accumulate, rows, C, mscale, mshift);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)dout,
                        (const bf16_t*)out, (const bf16_t*)y, mean, invstd, k1, k2, k3, (bf16_t*)dy, (bf16_t*)dres,
-                       dres_accumulate, rows, C);
+                       dres_accumulate, rows, C, mscale, mshift);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }

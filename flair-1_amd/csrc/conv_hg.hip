@@ -1,0 +1,334 @@
+// "Halo GEMM": 3x3 / stride-1 / pad-1 convolution (and its data gradient) for the MFMA-bound layers
+// (>= 64 channels: ResNet34 layer1-4 and decoder blocks 0-2; SURVEY.md §8a-3 = 57 % + 22 % of the FLOPs).
+//
+// The plain implicit GEMM re-gathers the im2col operand once per tap, i.e. 9x through the vector L1
+// (64 B/clk/CU), which — not the MFMA pipe — bounds it at ~64 FLOP per L1 byte.  Here a workgroup owns a
+// TW x TH output tile and, per 128-byte channel chunk, stages the (TH+2)x(TW+2) input halo ONCE in LDS
+// (prefetched in registers across the 9 tap steps of the previous chunk); all nine taps read their A
+// fragments from that halo with shifted addresses.  Only the weight tile [BN][128 B] per (tap, chunk) is
+// streamed (register-staged, double-buffered LDS).  Every wave owns a 64x64 accumulator tile.
+// Numerics, operand packing and epilogue (LDS transpose -> 16-byte NHWC stores, BN partial sums) are those
+// of conv_igemm.  Tile / buffering variants are template parameters; launch_conv_hg picks per layer.
+#include <stdlib.h>
+
+#include "common.h"
+#include "prof.h"
+
+namespace flair {
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct GMma;
+template <> struct GMma<bf16_t> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct GMma<float> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ int sw_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// TW x TH output pixels per workgroup (128 or 256), BN output channels (64 or 128), HB halo buffers (1 or 2)
+template <typename T, int TW, int TH, int BN, int HB>
+struct HgCfg {
+  static constexpr int CH = Elem<T>::CH;
+  static constexpr int CK = 8 * CH;                  // channels per 128-byte chunk (64 bf16 / 32 f32)
+  static constexpr int TPIX = TW * TH;
+  static constexpr int HW_ = TW + 2, HH = TH + 2, HPIX = HW_ * HH;
+  static constexpr int WMN = TPIX / 64, WNN = BN / 64;
+  static constexpr int NWAVE = WMN * WNN;
+  static constexpr int NT = 64 * NWAVE;
+  static constexpr int HALO = HPIX * 128;
+  static constexpr int BTILE = BN * 128;
+  static constexpr int CLD = BN * (int)sizeof(T) + 16;
+  static constexpr int CT = TPIX * CLD;
+  static constexpr int STAGES = HB * HALO + 2 * BTILE;
+  static constexpr int MAIN = STAGES > CT ? STAGES : CT;
+  static constexpr int STATS = WMN * BN * 2 * 4;
+  static constexpr int SMEM = MAIN + STATS;
+  static constexpr int HITEMS = (HPIX * 8 + NT - 1) / NT;
+  static constexpr int BITEMS = (BN * 8 + NT - 1) / NT;
+};
+
+template <typename T, int TW, int TH, int BN, int HB>
+__global__ __launch_bounds__(TW * TH * BN / 64) void conv3x3_hg_kernel(const ConvArgs a) {  // 64 * (TPIX/64) * (BN/64) threads
+  using Cfg = HgCfg<T, TW, TH, BN, HB>;
+  constexpr int CH = Cfg::CH, CK = Cfg::CK, HW_ = Cfg::HW_, HPIX = Cfg::HPIX, NT = Cfg::NT, TPIX = Cfg::TPIX;
+  constexpr int TM = 4, TN = 4, MTX = TW / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* halo0 = smem;
+  unsigned char* bt0 = smem + HB * Cfg::HALO;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wm = wave % Cfg::WMN, wn = wave / Cfg::WMN;
+  const int H = a.Hout, W = a.Wout;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  const int tile = blockIdx.x;
+  const int n = tile / (tiles_x * tiles_y);
+  const int trem = tile - n * tiles_x * tiles_y;
+  const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+  const int n0 = blockIdx.y * BN;
+  const int Cin = a.C0 + a.C1;
+  const T* __restrict__ src0 = (const T*)a.src0;
+  const T* __restrict__ src1 = (const T*)a.src1;
+  const T* __restrict__ wp = (const T*)a.w;
+  const int Hs0 = a.up0 ? (H >> 1) : H, Ws0 = a.up0 ? (W >> 1) : W;
+  const int nchunks = Cin / CK;
+
+  // ---- halo chunk: global -> registers (issued early), registers -> LDS (one chunk later)
+  u32x4 hreg[Cfg::HITEMS];
+  unsigned hmask[Cfg::HITEMS];
+  auto halo_load = [&](int chunk) {
+    const int cbase = chunk * CK;
+    const bool use0 = cbase < a.C0 || chunk >= nchunks;  // past-the-end prefetch: masked, but must read a valid base
+    const T* __restrict__ base = use0 ? src0 : src1;
+    const int Hs = use0 ? Hs0 : H, Ws = use0 ? Ws0 : W, Cs = use0 ? a.C0 : a.C1;
+    const int sh = (use0 && a.up0) ? 1 : 0;
+    const int coff = use0 ? cbase : cbase - a.C0;
+#pragma unroll
+    for (int k = 0; k < Cfg::HITEMS; ++k) {
+      const int it = t + NT * k;
+      const int hp = it >> 3, ch = it & 7;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = (it < HPIX * 8) && (chunk < nchunks) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+      const unsigned off = ok ? (unsigned)(((n * Hs + (iy >> sh)) * Ws + (ix >> sh)) * Cs + coff + ch * CH) : 0u;
+      hreg[k] = *reinterpret_cast<const u32x4*>(base + off);
+      hmask[k] = ok ? 0xffffffffu : 0u;
+    }
+  };
+  auto halo_store = [&](int buf) {
+    unsigned char* hb = halo0 + buf * Cfg::HALO;
+#pragma unroll
+    for (int k = 0; k < Cfg::HITEMS; ++k) {
+      const int it = t + NT * k;
+      if (it < HPIX * 8) *reinterpret_cast<u32x4*>(hb + sw_off(it >> 3, it & 7)) = hreg[k] & hmask[k];
+    }
+  };
+  // ---- weight tile of (chunk, tap): [BN][128 B]
+  u32x4 breg[Cfg::BITEMS];
+  auto b_load = [&](int step) {
+    const int total = nchunks * 9;
+    const int sc = step < total ? step : total - 1;
+    const int chunk = sc / 9, tap = sc - chunk * 9;
+#pragma unroll
+    for (int k = 0; k < Cfg::BITEMS; ++k) {
+      const int it = t + NT * k;
+      const int itc = it < BN * 8 ? it : 0;
+      breg[k] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + (itc >> 3)) * a.Kpad + tap * Cin + chunk * CK + (itc & 7) * CH);
+    }
+  };
+  auto b_store = [&](int buf) {
+    unsigned char* bb = bt0 + buf * Cfg::BTILE;
+#pragma unroll
+    for (int k = 0; k < Cfg::BITEMS; ++k) {
+      const int it = t + NT * k;
+      if ((BN * 8) % NT == 0 || it < BN * 8) *reinterpret_cast<u32x4*>(bb + sw_off(it >> 3, it & 7)) = breg[k];
+    }
+  };
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // halo pixel (tap 0,0) of this lane for m-tile i; m-tile g = wm*4+i covers 16 consecutive x of one tile row
+  int hp0[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int g = wm * 4 + i;
+    hp0[i] = (g / MTX) * HW_ + (g % MTX) * 16 + lr;
+  }
+
+  halo_load(0);
+  b_load(0);
+  halo_store(0);
+  b_store(0);
+  halo_load(1);   // chunk 1 (masked to nothing when there is a single chunk) rides in registers through chunk 0
+  __syncthreads();
+
+  int step = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const unsigned char* hb = halo0 + (HB == 2 ? (chunk & 1) : 0) * Cfg::HALO;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      b_load(step + 1);
+      const unsigned char* bb = bt0 + (step & 1) * Cfg::BTILE;
+      const int r = tap / 3, s = tap - 3 * r;
+      const int tapoff = r * HW_ + s;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(hb + sw_off(hp0[i] + tapoff, lq + 4 * h));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(bb + sw_off(wn * 64 + j * 16 + lr, lq + 4 * h));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) GMma<T>::run(af[i], bfr[j], acc[i][j]);
+      }
+      b_store((step + 1) & 1);
+      if (tap == 8) {
+        if constexpr (HB == 2) {   // next chunk's halo: landed long ago, becomes visible with this barrier
+          halo_store((chunk + 1) & 1);
+        } else {                   // single halo buffer: every wave must be done reading it first
+          __syncthreads();
+          halo_store(0);
+        }
+        halo_load(chunk + 2);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue (as conv_igemm)
+  unsigned char* ct = smem;
+  float* st = reinterpret_cast<float*>(smem + Cfg::MAIN);
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int q = 0; q < TN; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+#pragma unroll
+  for (int q = 0; q < TN; ++q) {
+    const int col = wn * 64 + q * 16 + lr;
+    const float bias = (a.bias && (n0 + col) < a.Cout) ? a.bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int g = wm * 4 + i;
+        const int row = (g / MTX) * TW + (g % MTX) * 16 + lq * 4 + rr;  // tile-local pixel
+        T v = Elem<T>::from_f(acc[i][q][rr] + bias);
+        const float vf = Elem<T>::to_f(v);
+        s1[q] += vf;
+        s2[q] += vf * vf;
+        *reinterpret_cast<T*>(ct + row * Cfg::CLD + col * (int)sizeof(T)) = v;
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int q = 0; q < TN; ++q) {
+      s1[q] += __shfl_xor(s1[q], 16); s1[q] += __shfl_xor(s1[q], 32);
+      s2[q] += __shfl_xor(s2[q], 16); s2[q] += __shfl_xor(s2[q], 32);
+      if (lq == 0) {
+        st[(wm * BN + wn * 64 + q * 16 + lr) * 2 + 0] = s1[q];
+        st[(wm * BN + wn * 64 + q * 16 + lr) * 2 + 1] = s2[q];
+      }
+    }
+  }
+  __syncthreads();
+  if (a.stats && t < BN && (n0 + t) < a.Cout) {
+    float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < Cfg::WMN; ++w) { x1 += st[(w * BN + t) * 2]; x2 += st[(w * BN + t) * 2 + 1]; }
+    a.stats[(long)(n0 + t) * gridDim.x + blockIdx.x] = x1;
+    a.stats[((long)a.Cout + n0 + t) * gridDim.x + blockIdx.x] = x2;
+  }
+  if (a.out) {
+    constexpr int CPR = BN / CH;
+    T* __restrict__ out = (T*)a.out;
+    for (int idx = t; idx < TPIX * CPR; idx += NT) {
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int py = row / TW, px = row - py * TW;
+      const int nn = n0 + ch * CH;
+      if (nn < a.Cout) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(ct + row * Cfg::CLD + ch * 16);
+        T* dst = out + ((long)(n * H + y0 + py) * W + x0 + px) * a.out_ld + nn;
+        if (a.accumulate) {
+          const uint4 o = *reinterpret_cast<const uint4*>(dst);
+          const uint4 vv = make_uint4(v.x, v.y, v.z, v.w);
+          float fa[CH], fb[CH];
+          chunk_to_f<T>(vv, fa);
+          chunk_to_f<T>(o, fb);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) fa[e] += fb[e];
+          const uint4 r = f_to_chunk<T>(fa);
+          v = u32x4{r.x, r.y, r.z, r.w};
+        }
+        *reinterpret_cast<u32x4*>(dst) = v;
+      }
+    }
+  }
+}
+
+int g_hg_variant = -1;  // tuning override (FLAIR_HG_VARIANT): 0 = 256 px x 8 waves, 1 = 128 px x 4 waves x 2 WG/CU
+
+template <typename T, int TW, int TH, int BN, int HB>
+int launch_hg_cfg(const ConvArgs& a, hipStream_t s) {
+  using Cfg = HgCfg<T, TW, TH, BN, HB>;
+  auto kern = conv3x3_hg_kernel<T, TW, TH, BN, HB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long M = (long)a.N * a.Hout * a.Wout;
+  dim3 grid((unsigned)(M / Cfg::TPIX), a.Cout / BN);
+  {
+    const double flops = 2.0 * (double)M * a.Cout * a.Kg;
+    const double bytes = ((double)M / (a.up0 ? 4 : 1) * a.C0 + (double)M * a.C1 + (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) +
+                         (double)a.Cout * a.Kg * sizeof(T);
+    static const char* names[2][2] = {{"conv3x3_hg_f32_n64", "conv3x3_hg_f32_n128"}, {"conv3x3_hg_bf16_n64", "conv3x3_hg_bf16_n128"}};
+    ProfScope ps(names[sizeof(T) == 2][BN == 128], flops, bytes, s);
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::SMEM, s, a);
+  }
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+// tile pixel count for this layer: 128-pixel tiles (2 workgroups per CU, de-phased barriers) unless the image
+// only tiles by 256; small layers also need the finer tiling to fill 256 CUs
+static int hg_tile_pixels(int dtype, const ConvArgs& a) {
+  (void)dtype;
+  if (g_hg_variant < 0) {
+    const char* e = getenv("FLAIR_HG_VARIANT");
+    g_hg_variant = e ? atoi(e) : 1;
+  }
+  const bool can128 = (a.Wout % 16 == 0) && (a.Hout % 8 == 0);
+  const bool can256 = (a.Wout % 32 == 0 && a.Hout % 8 == 0) || (a.Wout % 16 == 0 && a.Hout % 16 == 0);
+  if ((a.Cout % 128) != 0) return can256 ? 256 : (can128 ? 128 : 0);  // 64-wide: 4 waves x 256 px, single halo buffer
+  if (g_hg_variant == 0 && can256) return 256;
+  if (can128) return 128;
+  return can256 ? 256 : 0;
+}
+
+// 3x3 / stride 1 / pad 1, >= 64 output channels (multiple of 64), input channels in whole 128-byte chunks
+// per source, NHWC output (no fp32-NCHW head here).
+bool conv_hg_applicable(int dtype, const ConvArgs& a) {
+  const int ck = dtype == DT_F32 ? 32 : 64;
+  const int Cin = a.C0 + a.C1;
+  if (a.R != 3 || a.S != 3 || a.out_mul != 1 || a.in_div != 1 || a.pad != 1) return false;
+  if (a.Hout != a.Hin || a.Wout != a.Win || a.in_scale || a.out_nchw || !a.out) return false;
+  if ((Cin % ck) || (a.C0 % ck) || a.Cout < 64 || (a.Cout % 64)) return false;
+  return hg_tile_pixels(dtype, a) != 0;
+}
+
+int conv_hg_grid_rows(int dtype, const ConvArgs& a) { return (int)((long)a.N * a.Hout * a.Wout / hg_tile_pixels(dtype, a)); }
+
+template <typename T>
+static int launch_hg_t(int tp, const ConvArgs& a, hipStream_t s) {
+  const bool n128 = (a.Cout % 128) == 0;
+  if (tp == 128) return n128 ? launch_hg_cfg<T, 16, 8, 128, 2>(a, s) : launch_hg_cfg<T, 16, 8, 64, 2>(a, s);
+  if (a.Wout % 32 == 0) return n128 ? launch_hg_cfg<T, 32, 8, 128, 2>(a, s) : launch_hg_cfg<T, 32, 8, 64, 1>(a, s);
+  return n128 ? launch_hg_cfg<T, 16, 16, 128, 2>(a, s) : launch_hg_cfg<T, 16, 16, 64, 1>(a, s);
+}
+
+int launch_conv_hg(int dtype, const ConvArgs& a, hipStream_t s) {
+  const int tp = hg_tile_pixels(dtype, a);
+  return dtype == DT_F32 ? launch_hg_t<float>(tp, a, s) : launch_hg_t<bf16_t>(tp, a, s);
+}
+
+}  // namespace flair

@@ -46,7 +46,7 @@ struct ConvCfg {
 };
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   using Cfg = ConvCfg<T, BM, BN, WAVES_M, WAVES_N>;
   constexpr int CH = Cfg::CH, BKE = Cfg::BKE;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -100,15 +100,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   // Branch-free gather: every lane always issues its 16-byte load (out-of-image taps read the tensor base
   // and are zeroed by a select when the registers are written to LDS), so all loads of a K step are in
   // flight together behind one s_waitcnt instead of one memory round trip per row.
-  u32x4 areg[AROWS], breg[BROWS];
-  bool aok[AROWS];
-  auto load_regs = [&](int step) {
+  // Two register sets: the loads of K step s+2 are issued while step s is multiplied and are written to LDS
+  // one iteration later, so a load has a whole iteration (MFMA phase + barrier) to land instead of having
+  // to beat the MFMA phase of its own iteration.
+  struct Regs { u32x4 a[AROWS]; u32x4 b[BROWS]; unsigned m[AROWS]; };
+  auto load_regs = [&](int step, Regs& R) {
     const bool use0 = kc < a.C0;
     const T* __restrict__ base = use0 ? src0 : src1;
     const int Hs = use0 ? Hs0 : a.Hin, Ws = use0 ? Ws0 : a.Win, Cs = use0 ? a.C0 : a.C1;
     const int sh = (use0 && a.up0) ? 1 : 0;
     const int coff = use0 ? kc : kc - a.C0;
     const bool tap_ok = kr < a.R;
+    const int bstep = step < nsteps ? step : nsteps - 1;  // past the end: harmless re-read, never consumed
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       int hn = ih0[i] + kr, wq = iw0[i] + ks;
@@ -119,13 +122,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       }
       ok = ok && ((unsigned)hn < (unsigned)a.Hin) && ((unsigned)wq < (unsigned)a.Win);
       const unsigned off = ok ? (unsigned)(((nb[i] * Hs + (hn >> sh)) * Ws + (wq >> sh)) * Cs + coff) : 0u;
-      areg[i] = *reinterpret_cast<const u32x4*>(base + off);
-      aok[i] = ok;
+      R.a[i] = *reinterpret_cast<const u32x4*>(base + off);
+      R.m[i] = ok ? 0xffffffffu : 0u;
     }
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
       const int row = (BN >= 32) ? rb + 32 * j : (rb & (BN - 1));
-      breg[j] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + row) * a.Kpad + (long)step * BKE + cc * CH);
+      R.b[j] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + row) * a.Kpad + (long)bstep * BKE + cc * CH);
     }
     // advance the K decode by one step
     kc += BKE;
@@ -134,20 +137,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       if (++ks == a.S) { ks = 0; ++kr; }
     }
   };
-  auto write_lds = [&](int stage) {
+  auto write_lds = [&](int stage, const Regs& R) {
     unsigned char* sA = smem + stage * Cfg::STAGE;
     unsigned char* sB = sA + BM * 128;
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-      const unsigned m = aok[i] ? 0xffffffffu : 0u;
-      *reinterpret_cast<u32x4*>(sA + lds_off(rb + 32 * i, cc)) = areg[i] & m;
-    }
+    for (int i = 0; i < AROWS; ++i) *reinterpret_cast<u32x4*>(sA + lds_off(rb + 32 * i, cc)) = R.a[i] & R.m[i];
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
       if constexpr (BN >= 32) {
-        *reinterpret_cast<u32x4*>(sB + lds_off(rb + 32 * j, cc)) = breg[j];
+        *reinterpret_cast<u32x4*>(sB + lds_off(rb + 32 * j, cc)) = R.b[j];
       } else {
-        if (rb < BN) *reinterpret_cast<u32x4*>(sB + lds_off(rb, cc)) = breg[j];
+        if (rb < BN) *reinterpret_cast<u32x4*>(sB + lds_off(rb, cc)) = R.b[j];
       }
     }
   };
@@ -158,15 +158,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  load_regs(0);
-  write_lds(0);
-  __syncthreads();
   const int lr = lane & 15, lq = lane >> 4;
-  for (int step = 0; step < nsteps; ++step) {
-    const int cur = step & 1;
-    // unconditional prefetch (the last iteration re-reads its own weight step and taps beyond R, all
-    // zero-masked, into the stage nobody reads): keeps the loop body straight-line for the compiler
-    load_regs(step + 1 < nsteps ? step + 1 : step);
+  auto compute = [&](int cur) {
     const unsigned char* sA = smem + cur * Cfg::STAGE;
     const unsigned char* sB = sA + BM * 128;
 #pragma unroll
@@ -183,7 +176,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
     }
-    write_lds(cur ^ 1);
+  };
+
+  Regs r0, r1;
+  load_regs(0, r0);
+  write_lds(0, r0);
+  load_regs(1, r0);
+  __syncthreads();
+  for (int step = 0; step < nsteps; step += 2) {
+    load_regs(step + 2, r1);   // in flight across this iteration and the next barrier
+    compute(0);                // K step `step` (LDS stage 0)
+    write_lds(1, r0);          // K step `step + 1`, loaded one iteration ago
+    __syncthreads();
+    if (step + 1 >= nsteps) break;
+    load_regs(step + 3, r0);
+    compute(1);
+    write_lds(0, r1);
     __syncthreads();
   }
 
@@ -302,9 +310,12 @@ static inline int pick_bm(int cout) { return cout >= 64 ? 128 : 256; }
 bool conv_halo_applicable(const ConvArgs& a);           // conv_halo.hip
 int conv_halo_grid_rows(const ConvArgs& a);
 int launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s);
+bool conv_hg_applicable(int dtype, const ConvArgs& a);  // conv_hg.hip
+int conv_hg_grid_rows(int dtype, const ConvArgs& a);
+int launch_conv_hg(int dtype, const ConvArgs& a, hipStream_t s);
 
 int conv_grid_rows(int dtype, const ConvArgs& a) {
-  (void)dtype;
+  if (conv_hg_applicable(dtype, a)) return conv_hg_grid_rows(dtype, a);
   if (conv_halo_applicable(a)) return conv_halo_grid_rows(a);
   return cdiv((long)a.N * a.Hout * a.Wout, pick_bm(a.Cout));
 }
@@ -327,6 +338,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
+  if (conv_hg_applicable(dtype, a)) return launch_conv_hg(dtype, a, s);  // MFMA-bound 3x3 s1 layers: halo GEMM
   if (conv_halo_applicable(a)) {  // HBM-bound small-channel 3x3 layers: halo-tile direct kernel
     const int ch = dtype == DT_F32 ? 4 : 8;
     if (a.out && (a.Cout % ch)) return -3;

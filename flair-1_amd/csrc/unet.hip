@@ -374,8 +374,12 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
   void* dy = alloc((size_t)u.y.elems() * dtype_size(dtype));
   float* partial = alloc_f((long)bn_bwd_blocks(rows) * 2 * b.C);
   float* coef = alloc_f(3 * b.C);
-  RUN(bn_backward(dtype, dout, u.relu ? u.out.p : nullptr, u.y.p, u.mean, u.invstd, params_ + b.g_off, rows, b.C,
-                  partial, coef, grads_ + b.g_off, grads_ + b.b_off, 0, dy, dres, dres_acc ? 1 : 0, s_));
+  // ReLU mask: units without a residual recompute it from y (out > 0 <=> y*scale + shift > 0) and skip
+  // reading the activation tensor in both backward passes
+  const bool mask_from_y = u.relu && u.res_unit < 0 && !u.res.p;
+  RUN(bn_backward(dtype, dout, (u.relu && !mask_from_y) ? u.out.p : nullptr, u.y.p, u.mean, u.invstd, params_ + b.g_off,
+                  rows, b.C, partial, coef, grads_ + b.g_off, grads_ + b.b_off, 0, dy, dres, dres_acc ? 1 : 0,
+                  mask_from_y ? u.scale : nullptr, mask_from_y ? u.shift : nullptr, s_));
   // weight gradient
   WgradArgs w;
   memset(&w, 0, sizeof(w));

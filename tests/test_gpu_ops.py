@@ -36,6 +36,12 @@ CONV_CASES = [
     (1, 32, 32, 128, 32, 3, 1, 1),
     (2, 4, 4, 512, 512, 3, 1, 1),
     (1, 2, 2, 256, 512, 3, 2, 1),
+    # halo-GEMM kernel (3x3 s1, >= 64 channels, 8x32 / 16x16 tiles)
+    (1, 8, 32, 64, 64, 3, 1, 1),
+    (2, 16, 16, 128, 128, 3, 1, 1),
+    (1, 16, 64, 128, 256, 3, 1, 1),
+    (1, 8, 64, 64, 192, 3, 1, 1),
+    (1, 32, 16, 512, 128, 3, 1, 1),
 ]
 
 
@@ -67,6 +73,15 @@ def test_conv_upsample_concat_bias_head(dev, dtype):
     ref = F.conv2d(torch.cat([F.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1), _q(w, dtype), padding=1)
     y, _, _ = ops.conv2d_forward(_nhwc(x0, dtype, dev), w.to(dev), x1=_nhwc(x1, dtype, dev), up0=True)
     assert _rel(y.float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    # halo-GEMM path with two sources: 128 upsampled + 64 skip channels -> 128 (decoder block 2 shape)
+    x0 = _q(torch.randn(1, 128, 8, 16, generator=g), dtype)
+    x1 = _q(torch.randn(1, 64, 16, 32, generator=g), dtype)
+    w = torch.randn(128, 192, 3, 3, generator=g) / 42
+    ref = F.conv2d(torch.cat([F.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1), _q(w, dtype), padding=1)
+    y, _, st = ops.conv2d_forward(_nhwc(x0, dtype, dev), w.to(dev), x1=_nhwc(x1, dtype, dev), up0=True, want_stats=True)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert _rel(got, ref) < TOL[dtype]
+    assert _rel(st[0].cpu(), got.sum(dim=(0, 2, 3))) < 1e-4
     xh = _q(torch.randn(2, 16, 32, 32, generator=g), dtype)
     wh = torch.randn(13, 16, 3, 3, generator=g) / 12
     bh = torch.randn(13, generator=g)
