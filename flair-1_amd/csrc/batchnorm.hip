@@ -67,15 +67,20 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
 }
 
 // out = [relu]( y*scale + shift [+ res | + res*rscale + rshift] )
+// The grid stride (gridDim.x * 256) is a multiple of the chunks per row (a power of two <= 128), so a thread
+// always works on the same channel chunk; the coefficients are still re-read (L1 hits) every iteration
+// rather than kept in 30-40 VGPRs: measured, the lost occupancy costs a streaming kernel 1.5x.
 template <typename T>
-__global__ void bn_act_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
-                              const T* __restrict__ res, const float* __restrict__ rscale,
-                              const float* __restrict__ rshift, T* __restrict__ out, long rows, int C, int relu) {
+__global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const T* __restrict__ res,
+                                                     const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                     T* __restrict__ out, long rows, int C, int relu) {
   constexpr int CH = Elem<T>::CH;
   const int cpr = C / CH;
   const long total = rows * cpr;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % cpr) * CH;
+  const long first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(first % cpr) * CH;
+  for (long idx = first; idx < total; idx += (long)gridDim.x * blockDim.x) {
     float f[CH];
     chunk_to_f<T>(*reinterpret_cast<const uint4*>(y + idx * CH), f);
 #pragma unroll
@@ -98,7 +103,7 @@ __global__ void bn_act_kernel(const T* __restrict__ y, const float* __restrict__
   }
 }
 
-// partial[0][c][blk] = sum dz ; partial[1][c][blk] = sum dz * xhat ; dz = dout * (out > 0)
+// partial[0][c][blk] = sum dz ; partial[1][c][blk] = sum dz * y ; dz = dout * (out > 0)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
@@ -116,12 +121,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   float s1[CH], s2[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  float mu[CH], is[CH], ms[CH], mh[CH];
-#pragma unroll
-  for (int e = 0; e < CH; ++e) {
-    mu[e] = mean[c + e]; is[e] = invstd[c + e];
-    ms[e] = mscale ? mscale[c + e] : 0.f; mh[e] = mscale ? mshift[c + e] : 0.f;
-  }
+  // accumulates sum(dz) and sum(dz*y); the finalize kernel turns the latter into sum(dz*xhat) =
+  // invstd*(sum(dz*y) - mean*sum(dz)), so no per-channel constants are held in registers here
+  // (occupancy is what a streaming reduction lives on)
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
@@ -137,12 +139,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       for (int e = 0; e < CH; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
     } else if (mscale) {  // ReLU mask recomputed from the pre-BN tensor: out > 0  <=>  y*scale + shift > 0
 #pragma unroll
-      for (int e = 0; e < CH; ++e) d[e] = fmaf(yy[e], ms[e], mh[e]) > 0.f ? d[e] : 0.f;
+      for (int e = 0; e < CH; ++e) d[e] = fmaf(yy[e], mscale[c + e], mshift[c + e]) > 0.f ? d[e] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
       s1[e] += d[e];
-      s2[e] += d[e] * ((yy[e] - mu[e]) * is[e]);
+      s2[e] = fmaf(d[e], yy[e], s2[e]);
     }
   }
 #pragma unroll
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // grid = C
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              const float* __restrict__ mean,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                                               float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
   __shared__ double sh[4];
@@ -178,31 +181,35 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   double s1 = 0.0, s2 = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 256) { s1 += (double)p1[b]; s2 += (double)p2[b]; }
   const double a1 = block_sum_f64(s1, sh);
-  const double a2 = block_sum_f64(s2, sh);
+  const double a2 = (block_sum_f64(s2, sh) - (double)mean[c] * a1) * (double)invstd[c];  // sum dz*xhat
   if (threadIdx.x == 0) {
     if (dgamma) {
       dgamma[c] = accumulate ? dgamma[c] + (float)a2 : (float)a2;
       dbeta[c] = accumulate ? dbeta[c] + (float)a1 : (float)a1;
     }
-    k1[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
-    k2[c] = (float)(a1 / count);
-    k3[c] = (float)(a2 / count);
+    // dy = g*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)), xhat = (y - mu)*invstd  ->  A*dz + B*y + Cc
+    const float gi = (gamma ? gamma[c] : 1.f) * invstd[c];
+    const float m1 = (float)(a1 / count), m2 = (float)(a2 / count);
+    k1[c] = gi;
+    k2[c] = -gi * m2 * invstd[c];
+    k3[c] = gi * (m2 * invstd[c] * mean[c] - m1);
   }
 }
 
-// dy = k1*(dz - k2 - xhat*k3) ; optional dres (+)= dz
+// dy = A*dz + B*y + Cc (coefficients from bn_bwd_finalize_kernel) ; optional dres (+)= dz ; dz = dout * relu-mask
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ k1, const float* __restrict__ k2,
-                                    const float* __restrict__ k3, T* __restrict__ dy, T* __restrict__ dres,
-                                    int dres_accumulate, long rows, int C, const float* __restrict__ mscale,
-                                    const float* __restrict__ mshift) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                           const T* __restrict__ y, const float* __restrict__ k1,
+                                                           const float* __restrict__ k2, const float* __restrict__ k3,
+                                                           T* __restrict__ dy, T* __restrict__ dres, int dres_accumulate,
+                                                           long rows, int C, const float* __restrict__ mscale,
+                                                           const float* __restrict__ mshift) {
   constexpr int CH = Elem<T>::CH;
   const int cpr = C / CH;
   const long total = rows * cpr;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % cpr) * CH;
+  const long first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(first % cpr) * CH;  // loop-invariant: the grid stride is a multiple of cpr
+  for (long idx = first; idx < total; idx += (long)gridDim.x * blockDim.x) {
     float d[CH], yy[CH];
     chunk_to_f<T>(*reinterpret_cast<const uint4*>(dout + idx * CH), d);
     chunk_to_f<T>(*reinterpret_cast<const uint4*>(y + idx * CH), yy);
@@ -229,10 +236,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
     }
     float g[CH];
 #pragma unroll
-    for (int e = 0; e < CH; ++e) {
-      const float xh = (yy[e] - mean[c + e]) * invstd[c + e];
-      g[e] = k1[c + e] * (d[e] - k2[c + e] - xh * k3[c + e]);
-    }
+    for (int e = 0; e < CH; ++e) g[e] = fmaf(k1[c + e], d[e], fmaf(k2[c + e], yy[e], k3[c + e]));
     *reinterpret_cast<uint4*>(dy + idx * CH) = f_to_chunk<T>(g);
   }
 }
@@ -326,7 +330,7 @@ int bn_act(int dtype, const void* y, const float* scale, const float* shift, con
 
 int bn_bwd_blocks(long rows) {
   long b = (rows + 255) / 256;  // >= 256 rows per block
-  if (b > 1024) b = 1024;
+  if (b > 2048) b = 2048;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -394,18 +398,18 @@ int bn_backward(int dtype, const void* dout, const void* out, const void* y, con
   {
     ProfScope ps3("bn_bwd_finalize", 0.0, (double)nblk * 2 * C * 4.0, s);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, partial, nblk, C, (double)rows, gamma, invstd,
-                       dgamma, dbeta, accumulate_param, k1, k2, k3);
+                       mean, dgamma, dbeta, accumulate_param, k1, k2, k3);
   }
   FLAIR_CHECK_LAUNCH();
   const long total = rows * (C / ch);
   ProfScope ps2("bn_bwd_apply", 0.0, (double)rows * C * dtype_size(dtype) * ((out ? 3 : 2) + 1 + (dres ? 1 : 0)), s);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)dout,
-                       (const float*)out, (const float*)y, mean, invstd, k1, k2, k3, (float*)dy, (float*)dres,
+                       (const float*)out, (const float*)y, k1, k2, k3, (float*)dy, (float*)dres,
                        dres_accumulate, rows, C, mscale, mshift);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)dout,
-                       (const bf16_t*)out, (const bf16_t*)y, mean, invstd, k1, k2, k3, (bf16_t*)dy, (bf16_t*)dres,
+                       (const bf16_t*)out, (const bf16_t*)y, k1, k2, k3, (bf16_t*)dy, (bf16_t*)dres,
                        dres_accumulate, rows, C, mscale, mshift);
   FLAIR_CHECK_LAUNCH();
   return 0;

