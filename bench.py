@@ -210,7 +210,7 @@ def main():
                     gb = r["bytes"] / (r["ms"] / 1e3) / 1e9 if r["ms"] > 0 else 0
                     print(f"{r['kernel']:28s} {r['ms']:9.3f} ms {r['launches']:5d} launches {tf:8.1f} TFLOP/s {gb:9.1f} GB/s(alg)", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(2, args.size, args.classes, iters=6)
+            res["cpu_baseline"] = cpu_baseline(2, args.size, args.classes, iters=24)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.barrier()
