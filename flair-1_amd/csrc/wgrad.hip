@@ -278,6 +278,9 @@ static void wg_plan(int dtype, const WgradArgs& a, int& bmk, int& bnn, int& spli
 bool wgrad_halo_applicable(const WgradArgs& a);          // wgrad_halo.hip
 size_t wgrad_halo_workspace_bytes(const WgradArgs& a);
 int launch_wgrad_halo(int dtype, const WgradArgs& a, hipStream_t s);
+bool wgrad_big_applicable(int dtype, const WgradArgs& a);  // wgrad_hg.hip
+size_t wgrad_big_workspace_bytes(int dtype, const WgradArgs& a);
+int launch_wgrad_big(int dtype, const WgradArgs& a, hipStream_t s);
 
 void launch_wgrad_reduce(const float* partial, float* dw, int splits, int Cout, int Cout_pad, int Kpad, int Cin,
                          int Cin_real, int R, int S, int accumulate, hipStream_t s) {
@@ -290,6 +293,7 @@ void launch_wgrad_reduce(const float* partial, float* dw, int splits, int Cout, 
 }
 
 size_t wgrad_workspace_bytes(int dtype, const WgradArgs& a) {
+  if (wgrad_big_applicable(dtype, a)) return wgrad_big_workspace_bytes(dtype, a);
   if (wgrad_halo_applicable(a)) return wgrad_halo_workspace_bytes(a);
   int bmk, bnn, splits, Kg, Kpad, Cout_pad;
   long pps;
@@ -320,6 +324,7 @@ static int wg_launch(const WgKArgs& ka, int splits, hipStream_t s) {
 int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if ((a.C0 % ch) || (a.C1 % ch) || (a.dy_ld % ch)) return -2;
+  if (wgrad_big_applicable(dtype, a)) return launch_wgrad_big(dtype, a, s);  // MFMA-bound 3x3 s1 layers, >= 128 channels
   if (wgrad_halo_applicable(a)) return launch_wgrad_halo(dtype, a, s);  // HBM-bound small-channel 3x3 layers
   WgKArgs ka;
   ka.a = a;

@@ -244,7 +244,7 @@ static bool wg_halo_geom(const WgradArgs& a, int& CK, int& CO, int& nsplit, int&
   if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1) return false;
   if (a.Hout != a.Hin || a.Wout != a.Win || (a.Hin % TH) || (a.Win % TW)) return false;
   if (Cin == 16 && a.C1 == 0) CK = 16;
-  else if (Cin % 32 == 0 && a.C0 % 32 == 0 && Cin <= 128) CK = 32;
+  else if (Cin % 32 == 0 && a.C0 % 32 == 0 && Cin <= 256) CK = 32;
   else return false;
   if (a.Cout > 64 || (a.dy_ld % 16)) return false;
   Cout_pad = (int)round_up(a.Cout, 16);

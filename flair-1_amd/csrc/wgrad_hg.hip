@@ -1,0 +1,305 @@
+// Weight gradient of the 3x3 / stride-1 / pad-1 layers with many channels (ResNet34 layer2-4, decoder
+// blocks 0-1):  dW[k][(r,s)][c] = sum_p dY[p][k] * X[p + (r,s)][c].
+//
+// The GEMM formulation (wgrad.hip) re-gathers the im2col operand once per tap and re-reads dY once per
+// 128-column tile, ~64 FLOP per L1 byte.  Here a persistent workgroup of 8 waves keeps a whole
+// [CO output channels] x [9 taps x CK input channels] block of the gradient in registers (144 fp32
+// accumulator VGPRs per lane in bf16 mode) and walks 16x8-pixel tiles: per tile it stages the X halo
+// (18x10 pixels x 128 B) and the dY tile (128 pixels x 256 B) ONCE in double-buffered LDS; the nine taps
+// are shifted transposed reads (ds_read_b64_tr_b16) of the same halo.  Waves are arranged 4 (output-channel
+// groups) x 2 (input-channel halves) so that one A fragment feeds 18 MFMAs.  One fp32 slab per workgroup,
+// summed in a fixed order by wgrad_reduce_kernel.
+#include "common.h"
+#include "prof.h"
+
+namespace flair {
+
+void launch_wgrad_reduce(const float* partial, float* dw, int splits, int Cout, int Cout_pad, int Kpad, int Cin,
+                         int Cin_real, int R, int S, int accumulate, hipStream_t s);  // wgrad.hip
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int TW = 16, TH = 8, HW_ = TW + 2, HH = TH + 2, HPIX = HW_ * HH, TPIX = TW * TH;  // 180 halo / 128 tile pixels
+constexpr int NT = 512;
+
+template <typename T> struct BFrag;
+template <> struct BFrag<bf16_t> {
+  static constexpr int KSTEP = 32;
+  template <int STRIDE>
+  __device__ static __forceinline__ u32x4 load(const unsigned char* img, int row0, int cb, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + (row0 + 8 * g + q) * STRIDE + cb + 8 * p));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + (row0 + 8 * g + 4 + q) * STRIDE + cb + 8 * p));
+    u32x4 r;
+    r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+    r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+    r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+    r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+    return r;
+  }
+  __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct BFrag<float> {
+  static constexpr int KSTEP = 16;
+  template <int STRIDE>
+  __device__ static __forceinline__ u32x4 load(const unsigned char* img, int row0, int cb, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    u32x4 r;
+    r.x = *reinterpret_cast<const unsigned*>(img + (row0 + g) * STRIDE + cb + 4 * i);
+    r.y = *reinterpret_cast<const unsigned*>(img + (row0 + 4 + g) * STRIDE + cb + 4 * i);
+    r.z = *reinterpret_cast<const unsigned*>(img + (row0 + 8 + g) * STRIDE + cb + 4 * i);
+    r.w = *reinterpret_cast<const unsigned*>(img + (row0 + 12 + g) * STRIDE + cb + 4 * i);
+    return r;
+  }
+  __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+struct WgBigArgs {
+  const void* x0; const void* x1; int C0, C1, up0;
+  int N, H, W;
+  const void* dy; int dy_ld; int Cout;
+  float* partial;   // [gridDim.x][Cout][9*Cin] fp32
+  int Kg, ntiles;
+};
+
+template <typename T>
+struct WgBigCfg {
+  static constexpr int CH = Elem<T>::CH;
+  static constexpr int CK = 8 * CH;        // input channels per workgroup: 128 B per pixel
+  static constexpr int CO = 16 * CH;       // output channels per workgroup: 256 B per pixel
+  static constexpr int XSTRIDE = 128 + 16, DSTRIDE = 256 + 16;
+  static constexpr int XBYTES = HPIX * XSTRIDE, DBYTES = TPIX * DSTRIDE;
+  static constexpr int STAGE = XBYTES + DBYTES;
+  static constexpr int SMEM = 2 * STAGE;
+  static constexpr int COT = CO / 4 / 16, CIT = CK / 2 / 16;   // per-wave 16x16 blocks: bf16 2 x 2, f32 1 x 1
+  static constexpr int XITEMS = (HPIX * 8 + NT - 1) / NT;      // 3
+  static constexpr int DITEMS = (TPIX * 16) / NT;              // 4
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
+  using Cfg = WgBigCfg<T>;
+  constexpr int CH = Cfg::CH, CK = Cfg::CK, CO = Cfg::CO, COT = Cfg::COT, CIT = Cfg::CIT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wk = wave & 3, wc = wave >> 2;   // output-channel group (of 4), input-channel half (of 2)
+  const int H = a.H, W = a.W;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  const int cbase = blockIdx.y * CK, kbase = blockIdx.z * CO;
+  const T* __restrict__ x0 = (const T*)a.x0;
+  const T* __restrict__ x1 = (const T*)a.x1;
+  const T* __restrict__ dy = (const T*)a.dy;
+  const bool use0 = cbase < a.C0;
+  const T* __restrict__ xb = use0 ? x0 : x1;
+  const int Hs = (use0 && a.up0) ? (H >> 1) : H, Ws = (use0 && a.up0) ? (W >> 1) : W, Cs = use0 ? a.C0 : a.C1;
+  const int sh = (use0 && a.up0) ? 1 : 0;
+  const int coff = use0 ? cbase : cbase - a.C0;
+
+  f32x4_t acc[COT][CIT][9];
+#pragma unroll
+  for (int co = 0; co < COT; ++co)
+#pragma unroll
+    for (int ci = 0; ci < CIT; ++ci)
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) acc[co][ci][tp] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 xr[Cfg::XITEMS], dr[Cfg::DITEMS];
+  unsigned xm[Cfg::XITEMS];
+  auto load_tile = [&](int tile) {
+    const bool tok = tile < a.ntiles;
+    const int tl = tok ? tile : 0;
+    const int n = tl / (tiles_x * tiles_y);
+    const int trem = tl - n * tiles_x * tiles_y;
+    const int y0 = (trem / tiles_x) * TH, x0p = (trem % tiles_x) * TW;
+#pragma unroll
+    for (int k = 0; k < Cfg::XITEMS; ++k) {
+      const int it = t + NT * k;
+      const int hp = it >> 3, ch = it & 7;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = y0 - 1 + hy, ix = x0p - 1 + hx;
+      const bool ok = tok && (it < HPIX * 8) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+      const unsigned off = ok ? (unsigned)(((n * Hs + (iy >> sh)) * Ws + (ix >> sh)) * Cs + coff + ch * CH) : 0u;
+      xr[k] = *reinterpret_cast<const u32x4*>(xb + off);
+      xm[k] = ok ? 0xffffffffu : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < Cfg::DITEMS; ++k) {
+      const int it = t + NT * k;
+      const int px = it >> 4, ch = it & 15;
+      const int py = px / TW, pxx = px - py * TW;
+      const unsigned off = (unsigned)(((n * H + y0 + py) * W + x0p + pxx) * a.dy_ld + kbase + ch * CH);
+      dr[k] = *reinterpret_cast<const u32x4*>(dy + (tok ? off : 0u));
+      if (!tok) dr[k] = u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* xh = smem + buf * Cfg::STAGE;
+    unsigned char* dyt = xh + Cfg::XBYTES;
+#pragma unroll
+    for (int k = 0; k < Cfg::XITEMS; ++k) {
+      const int it = t + NT * k;
+      if (it < HPIX * 8) *reinterpret_cast<u32x4*>(xh + (it >> 3) * Cfg::XSTRIDE + (it & 7) * 16) = xr[k] & xm[k];
+    }
+#pragma unroll
+    for (int k = 0; k < Cfg::DITEMS; ++k) {
+      const int it = t + NT * k;
+      *reinterpret_cast<u32x4*>(dyt + (it >> 4) * Cfg::DSTRIDE + (it & 15) * 16) = dr[k];
+    }
+  };
+
+  load_tile(blockIdx.x);
+  store_tile(0);
+  __syncthreads();
+  int it = 0;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, ++it) {
+    load_tile(tile + gridDim.x);   // next tile rides in registers while this one is multiplied
+    const unsigned char* xh = smem + (it & 1) * Cfg::STAGE;
+    const unsigned char* dyt = xh + Cfg::XBYTES;
+    if constexpr (sizeof(T) == 2) {
+      // bf16: one MFMA K step = 32 pixels = tile rows y, y+1 (16 pixels each).  Lane (g,i) supplies the
+      // transposed-read addresses of pixels 8g+q and 8g+4+q of the step; in the halo image the second row
+      // starts HW_ pixels later, in the dense dY image 16 pixels later.
+      const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+      const int dpix = 8 * g + q;
+      const int xpix = (g >> 1) * HW_ + 8 * (g & 1) + q;
+      typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+      auto tr2 = [&](const unsigned char* lo_addr, int hi_delta) {
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo_addr));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo_addr + hi_delta));
+        u32x4 r;
+        r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+        r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+        r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+        r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+        return r;
+      };
+#pragma unroll 1
+      for (int y = 0; y < TH; y += 2) {
+        u32x4 af[COT];
+#pragma unroll
+        for (int co = 0; co < COT; ++co)
+          af[co] = tr2(dyt + (y * TW + dpix) * Cfg::DSTRIDE + (wk * COT + co) * 32 + 8 * p, 4 * Cfg::DSTRIDE);
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const int r = tp / 3, s = tp - 3 * r;
+#pragma unroll
+          for (int ci = 0; ci < CIT; ++ci) {
+            const u32x4 bf = tr2(xh + (xpix + (y + r) * HW_ + s) * Cfg::XSTRIDE + (wc * CIT + ci) * 32 + 8 * p, 4 * Cfg::XSTRIDE);
+#pragma unroll
+            for (int co = 0; co < COT; ++co) BFrag<T>::mma(af[co], bf, acc[co][ci][tp]);
+          }
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int y = 0; y < TH; ++y) {   // f32: K step = 16 pixels = one tile row
+        u32x4 af[COT];
+#pragma unroll
+        for (int co = 0; co < COT; ++co)
+          af[co] = BFrag<T>::template load<Cfg::DSTRIDE>(dyt, y * TW, (wk * COT + co) * 16 * (int)sizeof(T), lane);
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const int r = tp / 3, s = tp - 3 * r;
+#pragma unroll
+          for (int ci = 0; ci < CIT; ++ci) {
+            const u32x4 bf = BFrag<T>::template load<Cfg::XSTRIDE>(xh, (y + r) * HW_ + s, (wc * CIT + ci) * 16 * (int)sizeof(T), lane);
+#pragma unroll
+            for (int co = 0; co < COT; ++co) BFrag<T>::mma(af[co], bf, acc[co][ci][tp]);
+          }
+        }
+      }
+    }
+    store_tile((it + 1) & 1);
+    __syncthreads();
+  }
+
+  // every wave owns a disjoint block of the gradient: write the slab directly
+  const int Cin = a.C0 + a.C1;
+  float* __restrict__ part = a.partial + (long)blockIdx.x * a.Cout * a.Kg;
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int co = 0; co < COT; ++co)
+#pragma unroll
+    for (int ci = 0; ci < CIT; ++ci)
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = kbase + (wk * COT + co) * 16 + lq * 4 + e;
+          const int c = cbase + (wc * CIT + ci) * 16 + lr;
+          part[(long)k * a.Kg + tp * Cin + c] = acc[co][ci][tp][e];
+        }
+}
+
+}  // namespace
+
+static bool wg_big_geom(int dtype, const WgradArgs& a, int& nsplit) {
+  const int ck = dtype == DT_F32 ? 32 : 64, co = dtype == DT_F32 ? 64 : 128;
+  const int Cin = a.C0 + a.C1;
+  if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1) return false;
+  if (a.Hout != a.Hin || a.Wout != a.Win || (a.Hin % TH) || (a.Win % TW)) return false;
+  if ((Cin % ck) || (a.C0 % ck) || (a.Cout % co) || a.dy_ld != a.Cout) return false;
+  const long ntiles = (long)a.N * a.Hin * a.Win / TPIX;
+  const int per = (Cin / ck) * (a.Cout / co);
+  long ns = 256 / per;            // one 8-wave workgroup per CU
+  if (ns < 1) ns = 1;
+  if (ns > ntiles) ns = ntiles;
+  nsplit = (int)ns;
+  return true;
+}
+
+bool wgrad_big_applicable(int dtype, const WgradArgs& a) {
+  int ns;
+  return wg_big_geom(dtype, a, ns);
+}
+
+size_t wgrad_big_workspace_bytes(int dtype, const WgradArgs& a) {
+  int ns;
+  if (!wg_big_geom(dtype, a, ns)) return 0;
+  return (size_t)ns * a.Cout * 9 * (a.C0 + a.C1) * sizeof(float);
+}
+
+template <typename T>
+static int launch_big_t(const WgBigArgs& h, int nsplit, int Cin, hipStream_t s) {
+  using Cfg = WgBigCfg<T>;
+  auto kern = wgrad3x3_big_kernel<T>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(nsplit, Cin / Cfg::CK, h.Cout / Cfg::CO);
+  const double M = (double)h.N * h.H * h.W;
+  ProfScope ps(sizeof(T) == 2 ? "wgrad3x3_big_bf16" : "wgrad3x3_big_f32", 2.0 * M * h.Cout * 9.0 * Cin,
+               (M * h.dy_ld + M * (h.C0 / (h.up0 ? 4.0 : 1.0) + h.C1)) * sizeof(T), s);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), Cfg::SMEM, s, h);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_wgrad_big(int dtype, const WgradArgs& a, hipStream_t s) {
+  int nsplit;
+  if (!wg_big_geom(dtype, a, nsplit)) return -2;
+  const int Cin = a.C0 + a.C1;
+  WgBigArgs h;
+  h.x0 = a.x0; h.x1 = a.x1; h.C0 = a.C0; h.C1 = a.C1; h.up0 = a.up0; h.N = a.N; h.H = a.Hin; h.W = a.Win;
+  h.dy = a.dy; h.dy_ld = a.dy_ld; h.Cout = a.Cout; h.partial = a.partial; h.Kg = 9 * Cin;
+  h.ntiles = (int)((long)a.N * a.Hin * a.Win / TPIX);
+  const int rc = dtype == DT_F32 ? launch_big_t<float>(h, nsplit, Cin, s) : launch_big_t<bf16_t>(h, nsplit, Cin, s);
+  if (rc) return rc;
+  launch_wgrad_reduce(a.partial, a.dw, nsplit, a.Cout, a.Cout, 9 * Cin, Cin, a.Cin_real, 3, 3, a.accumulate, s);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace flair
