@@ -162,6 +162,8 @@ __global__ __launch_bounds__(TW * TH * BN / 64) void conv3x3_hg_kernel(const Con
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap, ++step) {
       b_load(step + 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top of the step: hipcc otherwise sinks the
+                                          // loads next to their ds_write and exposes the full L2 latency
       const unsigned char* bb = bt0 + (step & 1) * Cfg::BTILE;
       const int r = tap / 3, s = tap - 3 * r;
       const int tapoff = r * HW_ + s;

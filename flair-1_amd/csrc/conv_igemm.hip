@@ -185,11 +185,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   __syncthreads();
   for (int step = 0; step < nsteps; step += 2) {
     load_regs(step + 2, r1);   // in flight across this iteration and the next barrier
+    __builtin_amdgcn_sched_barrier(0);  // pin the prefetch ahead of the MFMA phase (hipcc would sink it)
     compute(0);                // K step `step` (LDS stage 0)
     write_lds(1, r0);          // K step `step + 1`, loaded one iteration ago
     __syncthreads();
     if (step + 1 >= nsteps) break;
     load_regs(step + 3, r0);
+    __builtin_amdgcn_sched_barrier(0);
     compute(1);
     write_lds(0, r1);
     __syncthreads();

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs ka) {
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
     load_regs(pbeg + (long)(step + 1) * BP);  // past the end every lane is masked: straight-line loop body
+    __builtin_amdgcn_sched_barrier(0);        // pin the prefetch ahead of the MFMA phase (hipcc would sink it)
     const unsigned char* base = smem + cur * Cfg::STAGE;
 #pragma unroll
     for (int kb = 0; kb < BP; kb += KSTEP) {

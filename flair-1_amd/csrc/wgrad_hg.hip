@@ -162,6 +162,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
   int it = 0;
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, ++it) {
     load_tile(tile + gridDim.x);   // next tile rides in registers while this one is multiplied
+    __builtin_amdgcn_sched_barrier(0);  // pin the prefetch ahead of the MFMA phase (hipcc would sink it)
     const unsigned char* xh = smem + (it & 1) * Cfg::STAGE;
     const unsigned char* dyt = xh + Cfg::XBYTES;
     if constexpr (sizeof(T) == 2) {
