@@ -59,7 +59,7 @@ struct HgCfg {
 };
 
 template <typename T, int TW, int TH, int BN, int HB>
-__global__ __launch_bounds__(TW * TH * BN / 64) void conv3x3_hg_kernel(const ConvArgs a) {  // 64 * (TPIX/64) * (BN/64) threads
+__global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const ConvArgs a) {  // 64 * (TPIX/64) * (BN/64) threads
   using Cfg = HgCfg<T, TW, TH, BN, HB>;
   constexpr int CH = Cfg::CH, CK = Cfg::CK, HW_ = Cfg::HW_, HPIX = Cfg::HPIX, NT = Cfg::NT, TPIX = Cfg::TPIX;
   constexpr int TM = 4, TN = 4, MTX = TW / 16;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(TW * TH * BN / 64) void conv3x3_hg_kernel(const Con
 
   // ---- halo chunk: global -> registers (issued early), registers -> LDS (one chunk later)
   u32x4 hreg[Cfg::HITEMS];
-  unsigned hmask[Cfg::HITEMS];
+  unsigned hbits = 0;   // bit k: item k is inside the image (else it is stored as zeros)
   auto halo_load = [&](int chunk) {
     const int cbase = chunk * CK;
     const bool use0 = cbase < a.C0 || chunk >= nchunks;  // past-the-end prefetch: masked, but must read a valid base
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(TW * TH * BN / 64) void conv3x3_hg_kernel(const Con
     const int Hs = use0 ? Hs0 : H, Ws = use0 ? Ws0 : W, Cs = use0 ? a.C0 : a.C1;
     const int sh = (use0 && a.up0) ? 1 : 0;
     const int coff = use0 ? cbase : cbase - a.C0;
+    unsigned hb2 = 0;
 #pragma unroll
     for (int k = 0; k < Cfg::HITEMS; ++k) {
       const int it = t + NT * k;
@@ -102,29 +103,35 @@ __global__ __launch_bounds__(TW * TH * BN / 64) void conv3x3_hg_kernel(const Con
       const bool ok = (it < HPIX * 8) && (chunk < nchunks) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
       const unsigned off = ok ? (unsigned)(((n * Hs + (iy >> sh)) * Ws + (ix >> sh)) * Cs + coff + ch * CH) : 0u;
       hreg[k] = *reinterpret_cast<const u32x4*>(base + off);
-      hmask[k] = ok ? 0xffffffffu : 0u;
+      hb2 |= (ok ? 1u : 0u) << k;
     }
+    hbits = hb2;
   };
   auto halo_store = [&](int buf) {
     unsigned char* hb = halo0 + buf * Cfg::HALO;
 #pragma unroll
     for (int k = 0; k < Cfg::HITEMS; ++k) {
       const int it = t + NT * k;
-      if (it < HPIX * 8) *reinterpret_cast<u32x4*>(hb + sw_off(it >> 3, it & 7)) = hreg[k] & hmask[k];
+      if (it < HPIX * 8) {
+        const int hp = it >> 3, hx = hp % HW_;
+        *reinterpret_cast<u32x4*>(hb + hp * 128 + (((it & 7) ^ (hx & 7)) << 4)) = hreg[k] & (0u - ((hbits >> k) & 1u));
+      }
     }
   };
   // ---- weight tile of (chunk, tap): [BN][128 B]
   u32x4 breg[Cfg::BITEMS];
-  auto b_load = [&](int step) {
-    const int total = nchunks * 9;
-    const int sc = step < total ? step : total - 1;
-    const int chunk = sc / 9, tap = sc - chunk * 9;
+  unsigned bgo[Cfg::BITEMS];   // per-thread element offset of its weight chunk(s) at (tap 0, chunk 0)
 #pragma unroll
-    for (int k = 0; k < Cfg::BITEMS; ++k) {
-      const int it = t + NT * k;
-      const int itc = it < BN * 8 ? it : 0;
-      breg[k] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + (itc >> 3)) * a.Kpad + tap * Cin + chunk * CK + (itc & 7) * CH);
-    }
+  for (int k = 0; k < Cfg::BITEMS; ++k) {
+    const int it = t + NT * k;
+    const int itc = it < BN * 8 ? it : 0;
+    bgo[k] = (unsigned)((n0 + (itc >> 3)) * a.Kpad + (itc & 7) * CH);
+  }
+  auto b_load = [&](int chunk, int tap) {   // wave-uniform (chunk, tap): one scalar offset for all lanes
+    const int cl = chunk < nchunks ? chunk : nchunks - 1;
+    const unsigned so = (unsigned)(tap * Cin + cl * CK);
+#pragma unroll
+    for (int k = 0; k < Cfg::BITEMS; ++k) breg[k] = *reinterpret_cast<const u32x4*>(wp + (bgo[k] + so));
   };
   auto b_store = [&](int buf) {
     unsigned char* bb = bt0 + buf * Cfg::BTILE;
@@ -141,45 +148,53 @@ __global__ __launch_bounds__(TW * TH * BN / 64) void conv3x3_hg_kernel(const Con
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // halo pixel (tap 0,0) of this lane for m-tile i; m-tile g = wm*4+i covers 16 consecutive x of one tile row
-  int hp0[TM];
+  // Fragment addresses, precomputed: the halo swizzle depends on the column only, so a tap (r,s) is
+  // acol[s][i] + r * (HW_*128); the h = 1 half is the same address with bit 6 flipped (chunk + 4).
+  unsigned acol[3][TM], bfo[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int g = wm * 4 + i;
-    hp0[i] = (g / MTX) * HW_ + (g % MTX) * 16 + lr;
+    const int py = g / MTX, px = (g % MTX) * 16 + lr;
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) acol[sx][i] = (unsigned)((py * HW_ + px + sx) * 128 + ((lq ^ ((px + sx) & 7)) << 4));
   }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bfo[j] = (unsigned)sw_off(wn * 64 + j * 16 + lr, lq);
 
   halo_load(0);
-  b_load(0);
+  b_load(0, 0);
   halo_store(0);
   b_store(0);
   halo_load(1);   // chunk 1 (masked to nothing when there is a single chunk) rides in registers through chunk 0
   __syncthreads();
 
-  int step = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const unsigned char* hb = halo0 + (HB == 2 ? (chunk & 1) : 0) * Cfg::HALO;
+    const int par = chunk & 1;   // 9 taps per chunk: the weight-stage parity flips from chunk to chunk
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap, ++step) {
-      b_load(step + 1);
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) {
+      const int tap = r * 3 + sx;
+      const int cur = (par + tap) & 1;
+      if (tap < 8) b_load(chunk, tap + 1); else b_load(chunk + 1, 0);
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top of the step: hipcc otherwise sinks the
                                           // loads next to their ds_write and exposes the full L2 latency
-      const unsigned char* bb = bt0 + (step & 1) * Cfg::BTILE;
-      const int r = tap / 3, s = tap - 3 * r;
-      const int tapoff = r * HW_ + s;
+      const unsigned char* bb = bt0 + cur * Cfg::BTILE;
+      const unsigned char* hbr = hb + r * (HW_ * 128);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         u32x4 af[TM], bfr[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(hb + sw_off(hp0[i] + tapoff, lq + 4 * h));
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(hbr + (acol[sx][i] ^ (h << 6)));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(bb + sw_off(wn * 64 + j * 16 + lr, lq + 4 * h));
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(bb + (bfo[j] ^ (h << 6)));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) GMma<T>::run(af[i], bfr[j], acc[i][j]);
       }
-      b_store((step + 1) & 1);
+      b_store(cur ^ 1);
       if (tap == 8) {
         if constexpr (HB == 2) {   // next chunk's halo: landed long ago, becomes visible with this barrier
           halo_store((chunk + 1) & 1);
@@ -190,6 +205,7 @@ __global__ __launch_bounds__(TW * TH * BN / 64) void conv3x3_hg_kernel(const Con
         halo_load(chunk + 2);
       }
       __syncthreads();
+    }
     }
   }
 
