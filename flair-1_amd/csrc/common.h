@@ -93,6 +93,12 @@ struct ConvArgs {
   // optional fused input transform on src0/src1: x' = relu(x*scale[c] + shift[c]) (per concatenated channel)
   const float* in_scale;
   const float* in_shift;
+  // optional fused output epilogue (inference: BatchNorm folded to a per-channel affine, residual, ReLU):
+  //   out = [relu]( acc * oscale[n] + oshift[n] (+ bias[n]) [+ ores] )
+  const float* oscale;
+  const float* oshift;
+  const void* ores;  // NHWC T, same shape / row stride as out
+  int orelu;
 };
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s);

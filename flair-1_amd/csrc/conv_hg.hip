@@ -218,14 +218,16 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const 
 #pragma unroll
   for (int q = 0; q < TN; ++q) {
     const int col = wn * 64 + q * 16 + lr;
-    const float bias = (a.bias && (n0 + col) < a.Cout) ? a.bias[n0 + col] : 0.f;
+    const bool cin_ok = (n0 + col) < a.Cout;
+    const float osc = (a.oscale && cin_ok) ? a.oscale[n0 + col] : 1.f;
+    const float bias = ((a.bias && cin_ok) ? a.bias[n0 + col] : 0.f) + ((a.oshift && cin_ok) ? a.oshift[n0 + col] : 0.f);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int g = wm * 4 + i;
         const int row = (g / MTX) * TW + (g % MTX) * 16 + lq * 4 + rr;  // tile-local pixel
-        T v = Elem<T>::from_f(acc[i][q][rr] + bias);
+        T v = Elem<T>::from_f(fmaf(acc[i][q][rr], osc, bias));
         const float vf = Elem<T>::to_f(v);
         s1[q] += vf;
         s2[q] += vf * vf;
@@ -261,7 +263,24 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const 
       const int nn = n0 + ch * CH;
       if (nn < a.Cout) {
         u32x4 v = *reinterpret_cast<const u32x4*>(ct + row * Cfg::CLD + ch * 16);
-        T* dst = out + ((long)(n * H + y0 + py) * W + x0 + px) * a.out_ld + nn;
+        const long goff = ((long)(n * H + y0 + py) * W + x0 + px) * a.out_ld + nn;
+        T* dst = out + goff;
+        if (a.ores || a.orelu) {
+          float fa[CH];
+          chunk_to_f<T>(make_uint4(v.x, v.y, v.z, v.w), fa);
+          if (a.ores) {
+            float fb[CH];
+            chunk_to_f<T>(*reinterpret_cast<const uint4*>((const T*)a.ores + goff), fb);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) fa[e] += fb[e];
+          }
+          if (a.orelu) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) fa[e] = fmaxf(fa[e], 0.f);
+          }
+          const uint4 r = f_to_chunk<T>(fa);
+          v = u32x4{r.x, r.y, r.z, r.w};
+        }
         if (a.accumulate) {
           const uint4 o = *reinterpret_cast<const uint4*>(dst);
           const uint4 vv = make_uint4(v.x, v.y, v.z, v.w);

@@ -225,6 +225,18 @@ int UNet::run_unit(int ci, int bi, const Act& in0, const Act& in1, bool up0, boo
   u.scale = alloc_f(b.C); u.shift = alloc_f(b.C); u.mean = alloc_f(b.C); u.invstd = alloc_f(b.C);
   ConvArgs a;
   fill_conv_args(a, c, in0, in1, up0, u.y, base_ + c.wf);
+  if (!training_) {
+    // inference: BatchNorm (running statistics) is a per-channel affine -> folded, together with the residual
+    // add and the ReLU, into the conv epilogue; the pre-BN tensor is never written
+    RUN(bn_eval_coeffs(b.C, params_ + b.g_off, params_ + b.b_off, buffers_ + b.rm_off, buffers_ + b.rv_off, 1e-5f,
+                       u.scale, u.shift, s_));
+    u.out = u.y;
+    a.oscale = u.scale; a.oshift = u.shift; a.orelu = relu ? 1 : 0;
+    a.ores = res_unit >= 0 ? units_[res_unit].out.p : res.p;
+    RUN(launch_conv(dtype, a, s_));
+    units_.push_back(u);
+    return (int)units_.size() - 1;
+  }
   const int nblk = conv_grid_rows(dtype, a);
   float* partial = training_ ? alloc_f((long)nblk * 2 * b.C) : nullptr;
   a.stats = partial;
