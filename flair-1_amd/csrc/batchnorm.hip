@@ -127,24 +127,41 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (long r = r0 + rl; r < r1; r += rl_n) {
-    const long off = r * C + c;
-    float d[CH], yy[CH];
-    chunk_to_f<T>(*reinterpret_cast<const uint4*>(dout + off), d);
-    chunk_to_f<T>(*reinterpret_cast<const uint4*>(y + off), yy);
-    if (out) {
-      float o[CH];
-      chunk_to_f<T>(*reinterpret_cast<const uint4*>(out + off), o);
+  // four rows per iteration, all 8-12 loads issued before the first use (branch-free: rows past the end are
+  // clamped to a valid row and weighted by zero)
+  for (long r = r0 + rl; r < r1; r += 4L * rl_n) {
+    uint4 dv[4], yv[4], ov[4];
+    float wgt[4];
 #pragma unroll
-      for (int e = 0; e < CH; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
-    } else if (mscale) {  // ReLU mask recomputed from the pre-BN tensor: out > 0  <=>  y*scale + shift > 0
-#pragma unroll
-      for (int e = 0; e < CH; ++e) d[e] = fmaf(yy[e], mscale[c + e], mshift[c + e]) > 0.f ? d[e] : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const long ru = r + (long)u * rl_n;
+      const bool ok = ru < r1;
+      const long off = (ok ? ru : r) * C + c;
+      dv[u] = *reinterpret_cast<const uint4*>(dout + off);
+      yv[u] = *reinterpret_cast<const uint4*>(y + off);
+      if (out) ov[u] = *reinterpret_cast<const uint4*>(out + off);
+      wgt[u] = ok ? 1.f : 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < CH; ++e) {
-      s1[e] += d[e];
-      s2[e] = fmaf(d[e], yy[e], s2[e]);
+    for (int u = 0; u < 4; ++u) {
+      float d[CH], yy[CH];
+      chunk_to_f<T>(dv[u], d);
+      chunk_to_f<T>(yv[u], yy);
+      if (out) {
+        float o[CH];
+        chunk_to_f<T>(ov[u], o);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+      } else if (mscale) {  // ReLU mask recomputed from the pre-BN tensor: out > 0  <=>  y*scale + shift > 0
+#pragma unroll
+        for (int e = 0; e < CH; ++e) d[e] = fmaf(yy[e], mscale[c + e], mshift[c + e]) > 0.f ? d[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        d[e] *= wgt[u];
+        s1[e] += d[e];
+        s2[e] = fmaf(d[e], yy[e], s2[e]);
+      }
     }
   }
 #pragma unroll
