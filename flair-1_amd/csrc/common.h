@@ -99,6 +99,13 @@ struct ConvArgs {
   const float* oshift;
   const void* ores;  // NHWC T, same shape / row stride as out
   int orelu;
+  // optional fused backward of "nearest x2 upsample + concat" (data gradient of a decoder conv1, halo-tile
+  // kernels only): columns [0, pool_c0) are 2x2 sum-pooled into `out` ([N][H/2][W/2][out_ld]), the remaining
+  // columns go to out_skip ([N][H][W][out_skip_ld]); pool_c0 is a multiple of the kernel's column tile
+  int pool_c0;
+  void* out_skip;
+  int out_skip_ld;
+  int skip_accumulate;
 };
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s);

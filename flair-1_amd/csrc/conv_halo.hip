@@ -9,6 +9,7 @@
 // (LDS transpose -> 16-byte NHWC stores / fp32 NCHW logits, BN partial sums) and numerics as conv_igemm.
 #include "common.h"
 #include "prof.h"
+#include "tile_store.h"
 
 namespace flair {
 namespace {
@@ -203,48 +204,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     a.stats[(long)(n0 + t) * gridDim.x + blockIdx.x] = x1;
     a.stats[((long)a.Cout + n0 + t) * gridDim.x + blockIdx.x] = x2;
   }
-  if (a.out) {
-    constexpr int CPR = BN / CH;
-    T* __restrict__ out = (T*)a.out;
-    for (int idx = t; idx < TH * TW * CPR; idx += 256) {
-      const int row = idx / CPR, ch = idx - row * CPR;
-      const int py = row / TW, px = row - py * TW;
-      const int nn = n0 + ch * CH;
-      if (nn < a.Cout) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(ct + row * Cfg::CLD + ch * 16);
-        const long goff = ((long)(n * H + y0 + py) * W + x0 + px) * a.out_ld + nn;
-        T* dst = out + goff;
-        if (a.ores || a.orelu) {
-          float fa[CH];
-          chunk_to_f<T>(make_uint4(v.x, v.y, v.z, v.w), fa);
-          if (a.ores) {
-            float fb[CH];
-            chunk_to_f<T>(*reinterpret_cast<const uint4*>((const T*)a.ores + goff), fb);
-#pragma unroll
-            for (int e = 0; e < CH; ++e) fa[e] += fb[e];
-          }
-          if (a.orelu) {
-#pragma unroll
-            for (int e = 0; e < CH; ++e) fa[e] = fmaxf(fa[e], 0.f);
-          }
-          const uint4 r = f_to_chunk<T>(fa);
-          v = u32x4{r.x, r.y, r.z, r.w};
-        }
-        if (a.accumulate) {
-          const uint4 o = *reinterpret_cast<const uint4*>(dst);
-          const uint4 vv = make_uint4(v.x, v.y, v.z, v.w);
-          float fa[CH], fb[CH];
-          chunk_to_f<T>(vv, fa);
-          chunk_to_f<T>(o, fb);
-#pragma unroll
-          for (int e = 0; e < CH; ++e) fa[e] += fb[e];
-          const uint4 r = f_to_chunk<T>(fa);
-          v = u32x4{r.x, r.y, r.z, r.w};
-        }
-        *reinterpret_cast<u32x4*>(dst) = v;
-      }
-    }
-  }
+  store_tile<T, TW, TH * TW, BN, 256, Cfg::CLD>(a, ct, n, y0, x0, n0, t);
   if (a.out_nchw) {
     const long HWp = (long)H * W;
     for (int idx = t; idx < TH * TW * BN; idx += 256) {

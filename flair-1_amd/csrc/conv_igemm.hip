@@ -329,6 +329,14 @@ bool conv_hg_applicable(int dtype, const ConvArgs& a);  // conv_hg.hip
 int conv_hg_grid_rows(int dtype, const ConvArgs& a);
 int launch_conv_hg(int dtype, const ConvArgs& a, hipStream_t s);
 
+// true when launch_conv will pick a halo-tile kernel whose epilogue implements pool_c0 / out_skip
+bool conv_tile_epilogue_ok(int dtype, const ConvArgs& a) {
+  if ((a.Hout & 1) || (a.Wout & 1)) return false;
+  if (conv_hg_applicable(dtype, a)) return a.pool_c0 % ((a.Cout % 128) == 0 ? 128 : 64) == 0;
+  if (conv_halo_applicable(a)) return a.pool_c0 % (a.Cout <= 16 ? 16 : 32) == 0 && !a.out_nchw;
+  return false;
+}
+
 int conv_grid_rows(int dtype, const ConvArgs& a) {
   if (conv_hg_applicable(dtype, a)) return conv_hg_grid_rows(dtype, a);
   if (conv_halo_applicable(a)) return conv_halo_grid_rows(a);
@@ -353,6 +361,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
+  if (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a)) return -6;
   if (conv_hg_applicable(dtype, a)) return launch_conv_hg(dtype, a, s);  // MFMA-bound 3x3 s1 layers: halo GEMM
   if (conv_halo_applicable(a)) {  // HBM-bound small-channel 3x3 layers: halo-tile direct kernel
     const int ch = dtype == DT_F32 ? 4 : 8;

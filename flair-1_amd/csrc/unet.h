@@ -135,7 +135,8 @@ class UNet {
   void encoder_fwd_impl(const float* x_nchw);
   void decoder_fwd_impl();
   void head_fwd_impl(float* logits_nchw);
-  void unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bool need_dgrad, void* dx_override);
+  void unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bool need_dgrad, void* dx_override,
+                     bool upcat = false);
   void head_bwd_impl(const void* dl);
   void decoder_bwd_impl();
   void encoder_bwd_impl();

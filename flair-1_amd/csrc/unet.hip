@@ -8,6 +8,7 @@
 namespace flair {
 
 int conv_weight_rows_pad(int cout);  // conv_igemm.hip
+bool conv_tile_epilogue_ok(int dtype, const ConvArgs& a);
 
 #define RUN(expr)                         \
   do {                                    \
@@ -378,7 +379,8 @@ int UNet::head_forward(const float* params, const float* x_nchw, float* logits_n
 // Backward of one conv->BN->(+res)->ReLU unit.  dout = gradient w.r.t. u.out (or w.r.t. the BN
 // output when the unit was not materialised).  Produces parameter gradients, optionally the
 // residual-branch gradient dz (dres) and the input gradient (into grad_of(in0) or dx_override).
-void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bool need_dgrad, void* dx_override) {
+void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bool need_dgrad, void* dx_override,
+                         bool upcat) {
   const Unit& u = units_[ui];
   const ConvDesc& c = convs[u.conv];
   const BnDesc& b = bns[u.bn];
@@ -416,6 +418,25 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
   a.Kg = c.Kgd; a.Kpad = c.Kpad_d;
   a.w = base_ + c.wd;
   a.out_ld = c.Cin_p;
+  if (upcat) {
+    // decoder conv1: the input was cat([up2(in0), in1]).  Halo-tile kernels pool / split the gradient in their
+    // epilogue; other shapes write the concatenated gradient and run the separate upcat_bwd pass.
+    const int C0 = u.in0.C, C1 = u.in1.p ? u.in1.C : 0;
+    bool acc0 = false, acc1 = false;
+    void* dx0 = grad_of(u.in0, &acc0);
+    void* dsk = C1 ? grad_of(u.in1, &acc1) : nullptr;
+    a.pool_c0 = C0; a.out = dx0; a.out_ld = C0; a.accumulate = acc0 ? 1 : 0;
+    a.out_skip = dsk; a.out_skip_ld = C1; a.skip_accumulate = acc1 ? 1 : 0;
+    if (conv_tile_epilogue_ok(dtype, a)) {
+      RUN(launch_conv(dtype, a, s_));
+    } else {
+      void* dcat = alloc((size_t)u.y.rows() * (C0 + C1) * dtype_size(dtype));
+      a.pool_c0 = 0; a.out_skip = nullptr; a.out = dcat; a.out_ld = C0 + C1; a.accumulate = 0;
+      RUN(launch_conv(dtype, a, s_));
+      RUN(upcat_bwd(dtype, dcat, dx0, acc0 ? 1 : 0, dsk, acc1 ? 1 : 0, u.y.N, u.y.H, u.y.W, C0, C1, s_));
+    }
+    return;
+  }
   if (dx_override) {
     a.out = dx_override; a.accumulate = 0;
   } else {
@@ -454,15 +475,8 @@ void UNet::decoder_bwd_impl() {
   for (int i = 4; i >= 0; --i) {
     const int u1 = dec_units_begin_ + 2 * i, u2 = u1 + 1;
     unit_backward(u2, grad_peek(units_[u2].out), nullptr, false, true, nullptr);
-    // conv1: gradient w.r.t. the virtual concat, then split: 2x2 sum-pool -> x, copy -> skip
-    const Unit& U = units_[u1];
-    const int C0 = U.in0.C, C1 = U.in1.p ? U.in1.C : 0;
-    void* dcat = alloc((size_t)U.y.rows() * (C0 + C1) * dtype_size(dtype));
-    unit_backward(u1, grad_peek(U.out), nullptr, false, true, dcat);
-    bool acc0 = false, acc1 = false;
-    void* dx0 = grad_of(U.in0, &acc0);
-    void* dsk = C1 ? grad_of(U.in1, &acc1) : nullptr;
-    RUN(upcat_bwd(dtype, dcat, dx0, acc0 ? 1 : 0, dsk, acc1 ? 1 : 0, U.y.N, U.y.H, U.y.W, C0, C1, s_));
+    // conv1: gradient w.r.t. the virtual concat: 2x2 sum-pool -> x, rest -> skip (fused in the epilogue)
+    unit_backward(u1, grad_peek(units_[u1].out), nullptr, false, true, nullptr, true);
   }
 }
 
