@@ -44,6 +44,17 @@ def collect_profile(L):
     return sorted(out, key=lambda r: -r["ms"])
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (scripts/pmc_traffic.py over rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None when no pass covers it."""
+    try:
+        import json as _j
+        t = _j.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")))
+        return t["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def host_cores():
     """CPU cores this process may actually use: cgroup quota (the GPU box gives a 16-core share of a big host),
     else the affinity mask."""
@@ -104,6 +115,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--train-only", action="store_true",
+                    help="skip the eval-mode inference leg (profiling runs: only train-step launches in the trace)")
     ap.add_argument("--kernels", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearse the RCCL gradient exchange (events, side stream, buckets) with a single rank")
@@ -156,11 +169,11 @@ def main():
     loss = float(trainer.loss.item())
 
     # inference tiles/s (eval-mode forward + argmax(softmax)), same tiles
-    for _ in range(2):
+    inf_iters = 0 if args.train_only else max(3, args.steps // 2)
+    for _ in range(2 if inf_iters else 0):
         trainer.predict(img)
     sync()
     t1 = time.perf_counter()
-    inf_iters = max(3, args.steps // 2)
     for _ in range(inf_iters):
         trainer.predict(img)
     sync()
@@ -182,7 +195,7 @@ def main():
                                    f"(fwd + fused CE/argmax/confmat + bwd + SGD), bs={args.batch}/GPU, random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "grad_allreduce": "none" if world == 1 else ("rccl bucketed, overlapped" if not args.no_overlap else "rccl bucketed")},
-            "inference_tiles_per_s": round(args.batch * world * inf_iters / dti, 2),
+            "inference_tiles_per_s": round(args.batch * world * inf_iters / dti, 2) if inf_iters else None,
             "train_tflops": round(value * TRAIN_GFLOP_PER_TILE / 1e3, 2),
             "frac_of_mfma_peak_whole_step": round(value * TRAIN_GFLOP_PER_TILE / 1e3 / (PEAK[args.dtype] * world), 4),
             "final_loss": round(loss, 5),
@@ -194,7 +207,10 @@ def main():
             if d["flops"] > 0:
                 ach = d["flops"] / d["launches"] / per_launch_s / 1e12
                 res["roofline"] = {"kernel": d["kernel"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.dtype],
-                                   "unit": "TFLOP/s", "frac": round(ach / PEAK[args.dtype], 4), "traffic": None,
+                                   "unit": "TFLOP/s", "frac": round(ach / PEAK[args.dtype], 4),
+                                   "traffic": pmc_traffic(d["kernel"]) if args.dtype == "bf16" and args.batch == 32 and args.size == 512 else None,
+                                   "traffic_unit": "HBM bytes/launch (PMC, profiles/r1_pmc_traffic.json)",
+                                   "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                                    "launches_per_step": d["launches"], "avg_launch_us": round(per_launch_s * 1e6, 2),
                                    "share_of_kernel_time": round(d["ms"] / tot, 3)}
             else:

@@ -234,7 +234,7 @@ int pack_weights_all(int dtype, const float* params, void* base, const PackTable
   double bytes = 0;
   for (int i = 0; i < tb.n; ++i) bytes += (double)tb.d[i].Cout * tb.d[i].Cin * tb.d[i].R * tb.d[i].S * 4.0 + (double)tb.d[i].rows_pad * tb.d[i].Kpad * dtype_size(dtype);
   ProfScope ps("pack_weights_all", 0.0, bytes, s);
-  dim3 grid(64, tb.n);
+  dim3 grid(256, tb.n);
   if (dtype == DT_F32)
     hipLaunchKernelGGL(pack_weights_all_kernel<float>, grid, dim3(256), 0, s, params, (unsigned char*)base, tb);
   else
