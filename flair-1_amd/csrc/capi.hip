@@ -129,6 +129,32 @@ int flair_jaccard(const int64_t* confmat, int C, float* per_class, float* weight
   if (!confmat) return -1;
   return jaccard_from_confmat((const long long*)confmat, C, per_class, weighted, macro, (hipStream_t)stream);
 }
+int flair_feed_tiles(const uint8_t* img_u8, const uint8_t* msk_raw, const uint8_t* d4_flags, int B, int bands, int H, int W,
+                     const int* channels, int n_channels, int norm_type, const double* means, const double* stds,
+                     int num_classes, float* img_out, uint8_t* labels_out, void* stream) {
+  if (!img_out && !labels_out) return -1;
+  if (n_channels < 0 || n_channels > FeedArgs::MAXCH) return -2;
+  if (img_out && (!img_u8 || !channels || n_channels < 1)) return -1;
+  if (norm_type == 2 && (!means || !stds)) return -1;
+  FeedArgs a{};
+  a.img = img_u8; a.msk = msk_raw; a.d4 = d4_flags; a.out = img_out; a.labels = labels_out;
+  a.B = B; a.Cb = bands; a.Cout = img_out ? n_channels : 0; a.H = H; a.W = W; a.mode = norm_type; a.num_classes = num_classes;
+  for (int c = 0; c < a.Cout; ++c) {
+    a.band[c] = channels[c] - 1;  // config "channels" start at 1 (rasterio band numbering)
+    a.mean[c] = norm_type == 2 ? means[c] : 0.0;
+    a.stdv[c] = norm_type == 2 ? stds[c] : 1.0;
+  }
+  return feed_tiles(a, (hipStream_t)stream);
+}
+int flair_detect_convert(const float* logits_nchw, int B, int C, int S, int margin, int output_type, void* out, void* stream) {
+  if (!logits_nchw || !out) return -1;
+  return detect_convert(logits_nchw, B, C, S, margin, output_type, out, (hipStream_t)stream);
+}
+int flair_confmat_masks(const uint8_t* truth_raw, const uint8_t* pred, int64_t n, int C, int truth_offset, int64_t* confmat,
+                        void* stream) {
+  if (!truth_raw || !pred || !confmat) return -1;
+  return confmat_masks(truth_raw, pred, n, C, truth_offset, (long long*)confmat, (hipStream_t)stream);
+}
 int flair_sgd_step(float* params, const float* grads, int64_t n, float lr, void* stream) {
   if (!params || !grads) return -1;
   return sgd_step(params, grads, n, lr, (hipStream_t)stream);

@@ -1,0 +1,191 @@
+// The rows either side of the U-Net hot path, as HBM-bound byte kernels:
+//   feed_tiles      uint8 raster bands (+ raw uint8 label raster) -> the batch the step consumes: band
+//                   selection, normalisation ('custom' in fp64 like numpy, 'scaling', 'without'), the D4
+//                   augmentation (V-flip, H-flip, rot90^k) and label decoding, in one pass.
+//                   src/flair/data_loader.py:9-30,65-95; src/flair/tasks_utils.py:37-41.
+//   detect_convert  softmax -> margin crop -> convert('argmax' | 'class_prob') of zone_detect.
+//                   src/zone_detect/compare.py:35,71-76; src/zone_detect/dataset.py:11-34.
+//   confmat_masks   offline evaluation: confusion matrix of (truth raster - 1) against a prediction raster.
+//                   src/flair/metrics.py:60-75.
+#include "ops.h"
+#include "prof.h"
+
+namespace flair {
+
+namespace {
+
+constexpr int MAXC = 32;
+
+// where output pixel (i, j) of rot90^k(hflip(vflip(a))) comes from (numpy: rot90 is counter-clockwise,
+// r[i][j] = m[j][N-1-i]); flags: bit0 V-flip, bit1 H-flip, bits 2-3 k
+__device__ __forceinline__ void d4_source(int flags, int i, int j, int H, int W, int& si, int& sj) {
+  const int k = (flags >> 2) & 3;
+  if (k == 0) { si = i; sj = j; }
+  else if (k == 1) { si = j; sj = W - 1 - i; }
+  else if (k == 2) { si = H - 1 - i; sj = W - 1 - j; }
+  else { si = H - 1 - j; sj = i; }
+  if (flags & 2) sj = W - 1 - sj;
+  if (flags & 1) si = H - 1 - si;
+}
+
+__device__ __forceinline__ float norm_byte(int mode, unsigned char v, double mean, double stdv) {
+  if (mode == 2) return (float)(((double)v - mean) / stdv);  // numpy: float64 subtract, float64 divide, then float32
+  if (mode == 1) return (float)((double)v * (1.0 / 255.0));  // skimage img_as_float(uint8), then float32
+  return (float)v;
+}
+
+__global__ __launch_bounds__(256) void feed_tiles_kernel(FeedArgs a) {
+  const int W4 = a.W / 4;
+  const long per_img = (long)a.H * W4;
+  const long total = per_img * a.B;
+  const long HW = (long)a.H * a.W;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(t / per_img);
+    const long r = t - (long)b * per_img;
+    const int i = (int)(r / W4), j0 = (int)(r - (long)i * W4) * 4;
+    const int flags = a.d4 ? a.d4[b] : 0;
+    long src[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int si, sj;
+      d4_source(flags, i, j0 + e, a.H, a.W, si, sj);
+      src[e] = (long)si * a.W + sj;
+    }
+    if (a.out) {
+      for (int c = 0; c < a.Cout; ++c) {
+        const unsigned char* p = a.img + ((long)b * a.Cb + a.band[c]) * HW;
+        const double m = a.mean[c], sd = a.stdv[c];
+        float4 o;
+        o.x = norm_byte(a.mode, p[src[0]], m, sd);
+        o.y = norm_byte(a.mode, p[src[1]], m, sd);
+        o.z = norm_byte(a.mode, p[src[2]], m, sd);
+        o.w = norm_byte(a.mode, p[src[3]], m, sd);
+        *reinterpret_cast<float4*>(a.out + ((long)b * a.Cout + c) * HW + (long)i * a.W + j0) = o;
+      }
+    }
+    if (a.labels) {
+      const unsigned char* p = a.msk + (long)b * HW;
+      unsigned int packed = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // read_msk: (raw - 1) in uint8, one-hot over range(C); argmax of an all-zero one-hot is class 0
+        const unsigned char v = (unsigned char)(p[src[e]] - 1);
+        packed |= (unsigned int)(v < a.num_classes ? v : 0) << (8 * e);
+      }
+      *reinterpret_cast<unsigned int*>(a.labels + (long)b * HW + (long)i * a.W + j0) = packed;
+    }
+  }
+}
+
+// one thread per kept pixel; logits NCHW fp32, so a wave reads 256 contiguous bytes per class plane
+__global__ __launch_bounds__(256) void detect_convert_kernel(const float* __restrict__ logits, int B, int C, int S, int margin,
+                                                             int mode, void* __restrict__ out) {
+  const int K = S - 2 * margin;
+  const long KK = (long)K * K, SS = (long)S * S, total = KK * B;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(t / KK);
+    const long r = t - (long)b * KK;
+    const int i = (int)(r / K), j = (int)(r - (long)i * K);
+    const float* p = logits + (long)b * C * SS + (long)(i + margin) * S + (j + margin);
+    float x[MAXC];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) { x[c] = p[(long)c * SS]; m = fmaxf(m, x[c]); }
+    float ssum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) { x[c] = expf(x[c] - m); ssum += x[c]; }
+    if (mode == 0) {  // convert('argmax'): [first argmax as float32, max probability]
+      int best = 0;
+      float pbest = -1.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) {
+          const float q = x[c] / ssum;
+          if (q > pbest) { pbest = q; best = c; }
+        }
+      float* o = reinterpret_cast<float*>(out) + (long)b * 2 * KK + r;
+      o[0] = (float)best;
+      o[KK] = pbest;
+    } else {  // convert('class_prob'): (p * 255).astype(uint8) — truncation
+      unsigned char* o = reinterpret_cast<unsigned char*>(out) + (long)b * C * KK + r;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) o[(long)c * KK] = (unsigned char)((x[c] / ssum) * 255.f);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void confmat_masks_kernel(const unsigned char* __restrict__ truth, const unsigned char* __restrict__ pred,
+                                                            long n, int C, int truth_offset, long long* __restrict__ confmat) {
+  __shared__ unsigned int hist[MAXC * MAXC];
+  for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0;
+  __syncthreads();
+  const long n16 = n / 16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+    const uint4 tv = reinterpret_cast<const uint4*>(truth)[i], pv = reinterpret_cast<const uint4*>(pred)[i];
+    const unsigned int tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      // numpy: uint8 raster - 1 wraps 0 -> 255; sklearn drops pairs with a member outside range(C)
+      const unsigned int t = ((tw[e >> 2] >> (8 * (e & 3))) + (unsigned)truth_offset) & 0xffu;
+      const unsigned int p = (pw[e >> 2] >> (8 * (e & 3))) & 0xffu;
+      if (t < (unsigned)C && p < (unsigned)C) atomicAdd(&hist[t * C + p], 1u);
+    }
+  }
+  if (blockIdx.x == 0)
+    for (long i = n16 * 16 + threadIdx.x; i < n; i += 256) {
+      const unsigned int t = ((unsigned)truth[i] + (unsigned)truth_offset) & 0xffu, p = pred[i];
+      if (t < (unsigned)C && p < (unsigned)C) atomicAdd(&hist[t * C + p], 1u);
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * C; i += 256) {
+    const unsigned int v = hist[i];
+    if (v) atomicAdd(reinterpret_cast<unsigned long long*>(confmat + i), (unsigned long long)v);
+  }
+}
+
+inline int stream_blocks(long items) {
+  long b = (items + 255) / 256;
+  if (b > 256 * 8) b = 256 * 8;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+int feed_tiles(const FeedArgs& a, hipStream_t s) {
+  if (a.B < 1 || a.H < 1 || a.W < 4 || (a.W & 3) || a.Cout < 0 || a.Cout > FeedArgs::MAXCH || a.mode < 0 || a.mode > 2) return -2;
+  if (a.out && (!a.img || a.Cout < 1)) return -2;
+  if (a.labels && (!a.msk || a.num_classes < 1 || a.num_classes > 255)) return -2;
+  if (a.d4 && a.H != a.W) return -2;  // rot90 of a non-square tile changes its shape
+  for (int c = 0; c < a.Cout; ++c)
+    if (a.band[c] < 0 || a.band[c] >= a.Cb) return -2;
+  const long px = (long)a.B * a.H * a.W;
+  ProfScope ps("feed_tiles", 0.0, (double)px * ((a.out ? 5.0 * a.Cout : 0.0) + (a.labels ? 2.0 : 0.0)), s);
+  hipLaunchKernelGGL(feed_tiles_kernel, dim3(stream_blocks(px / 4)), dim3(256), 0, s, a);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int detect_convert(const float* logits, int B, int C, int S, int margin, int mode, void* out, hipStream_t s) {
+  if (C < 1 || C > MAXC || B < 1 || margin < 0 || S - 2 * margin < 1 || mode < 0 || mode > 1) return -2;
+  const long K = S - 2 * margin;
+  ProfScope ps("detect_convert", 0.0, (double)B * K * K * (4.0 * C + (mode ? C : 8.0)), s);
+  hipLaunchKernelGGL(detect_convert_kernel, dim3(stream_blocks((long)B * K * K)), dim3(256), 0, s, logits, B, C, S, margin, mode, out);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int confmat_masks(const unsigned char* truth, const unsigned char* pred, long n, int C, int truth_offset, long long* confmat,
+                  hipStream_t s) {
+  if (C < 1 || C > MAXC || n < 0) return -2;
+  if (((uintptr_t)truth | (uintptr_t)pred) & 15) return -2;
+  if (n == 0) return 0;
+  ProfScope ps("confmat_masks", 0.0, 2.0 * (double)n, s);
+  hipLaunchKernelGGL(confmat_masks_kernel, dim3(stream_blocks(n / 16)), dim3(256), 0, s, truth, pred, n, C, truth_offset, confmat);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace flair

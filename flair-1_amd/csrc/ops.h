@@ -75,4 +75,23 @@ int confmat_update(const void* target, int target_kind, const void* pred, int pr
                    long long* confmat, hipStream_t s);
 int jaccard_from_confmat(const long long* confmat, int C, float* per_class, float* weighted, float* macro, hipStream_t s);
 
+// ---- feed.hip (rows either side of the hot path)
+struct FeedArgs {
+  static constexpr int MAXCH = 16;
+  const unsigned char* img;     // [B][Cb][H][W] raster bands as stored
+  const unsigned char* msk;     // optional [B][H][W] raw label raster (values 1..C as stored)
+  const unsigned char* d4;      // optional [B] per-sample draw: bit0 V-flip, bit1 H-flip, bits 2-3 rot90 count
+  float* out;                   // optional [B][Cout][H][W] fp32 NCHW (batch["img"])
+  unsigned char* labels;        // optional [B][H][W] class index = argmax(batch["msk"], 1)
+  int B, Cb, Cout, H, W;
+  int mode;                     // 0 'without', 1 'scaling', 2 'custom'
+  int num_classes;
+  int band[MAXCH];              // 0-based band of output channel c (config "channels" minus one)
+  double mean[MAXCH], stdv[MAXCH];
+};
+int feed_tiles(const FeedArgs& a, hipStream_t s);
+int detect_convert(const float* logits, int B, int C, int S, int margin, int mode, void* out, hipStream_t s);
+int confmat_masks(const unsigned char* truth, const unsigned char* pred, long n, int C, int truth_offset, long long* confmat,
+                  hipStream_t s);
+
 }  // namespace flair

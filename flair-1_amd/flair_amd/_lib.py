@@ -44,6 +44,10 @@ PROTOTYPES = {
     "flair_softmax_argmax": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "flair_confmat_update": (i32, [vp, i32, vp, i32, i64, i32, vp, vp]),
     "flair_jaccard": (i32, [vp, i32, vp, vp, vp, vp]),
+    "flair_confmat_masks": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+    "flair_feed_tiles": (i32, [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), i32, i32, C.POINTER(C.c_double),
+                               C.POINTER(C.c_double), i32, vp, vp, vp]),
+    "flair_detect_convert": (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
     "flair_sgd_step": (i32, [vp, vp, i64, f32, vp]),
     "flair_add_rowvec_nchw": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "flair_conv2d_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32]),

@@ -97,10 +97,37 @@ int flair_softmax_argmax(const float* logits_nchw, int B, int C, int H, int W, u
  * kinds: 0 uint8, 1 int32, 2 int64. */
 int flair_confmat_update(const void* target, int target_kind, const void* pred, int pred_kind, int64_t n, int C,
                          int64_t* confmat, void* stream);
+/* Offline evaluation: sum over tiles of sklearn.confusion_matrix((truth - 1).flatten(), pred.flatten(),
+ * labels=range(C)) — src/flair/metrics.py:60-75.  truth_offset is added to the truth byte with uint8
+ * wrap-around (-1: a stored 0 becomes 255); pairs with a member outside range(C) are dropped.  Both rasters
+ * 16-byte aligned. */
+int flair_confmat_masks(const uint8_t* truth_raw, const uint8_t* pred, int64_t n, int C, int truth_offset, int64_t* confmat,
+                        void* stream);
 /* MulticlassJaccardIndex.compute (average None / 'weighted' / 'macro') — task_module.py:36-51,90,113-114. */
 int flair_jaccard(const int64_t* confmat, int C, float* per_class, float* weighted, float* macro, void* stream);
 
 /* torch.optim.SGD(lr) step, no momentum / weight decay — tasks_utils.py:95. */
+/* ------------------------------------------------------------------------------------------------
+ * Input contract of the step on device: what fit_dataset.__getitem__ /
+ * predict_dataset.__getitem__ (src/flair/data_loader.py:74-95,130-144) and the augmentation set of
+ * src/flair/tasks_utils.py:37-41 do per tile on CPU workers, for a whole batch of stored uint8 rasters.
+ *   img_u8 (B, bands, H, W): bands as stored; channels[n_channels] = the config's 1-based band list
+ *   norm_type 0 'without' | 1 'scaling' (x * (1/255) in fp64) | 2 'custom' ((x - mean) / std in fp64), then fp32
+ *     — data_loader.py:9-30
+ *   msk_raw (B, H, W): stored label raster; labels_out = argmax over the one-hot of (raw - 1) (data_loader.py:65-69,
+ *     task_module.py:71): raw 1..C -> 0..C-1, anything else -> class 0
+ *   d4_flags (B) or null: bit0 VerticalFlip, bit1 HorizontalFlip, bits 2-3 RandomRotate90 factor, applied in that
+ *     order to image and labels alike; needs H == W.
+ * img_out (B, n_channels, H, W) fp32 NCHW and/or labels_out (B, H, W) uint8; either may be null. W % 4 == 0. */
+int flair_feed_tiles(const uint8_t* img_u8, const uint8_t* msk_raw, const uint8_t* d4_flags, int B, int bands, int H, int W,
+                     const int* channels, int n_channels, int norm_type, const double* means, const double* stds,
+                     int num_classes, float* img_out, uint8_t* labels_out, void* stream);
+/* zone_detect: softmax over classes (src/zone_detect/compare.py:35), margin crop (compare.py:71-75) and
+ * convert (src/zone_detect/dataset.py:11-34) without the probability tensor ever leaving the device.
+ * output_type 0 'argmax': out fp32 (B, 2, S-2m, S-2m) = [first argmax, max probability];
+ * output_type 1 'class_prob': out uint8 (B, C, S-2m, S-2m) = trunc(p * 255). */
+int flair_detect_convert(const float* logits_nchw, int B, int C, int S, int margin, int output_type, void* out, void* stream);
+
 int flair_sgd_step(float* params, const float* grads, int64_t n, float lr, void* stream);
 /* feats[-1] += x_enc.unsqueeze(1).unsqueeze(-1).repeat(1,512,1,16) — model.py:59-60: x (N,C,H,W) += v (N,H). */
 int flair_add_rowvec_nchw(float* x, const float* v, int N, int C, int H, int W, void* stream);
