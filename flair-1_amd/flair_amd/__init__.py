@@ -10,9 +10,9 @@ from .head import FusedCrossEntropyLoss, MulticlassJaccardIndex, MeanMetric
 from .task_module import segmentation_task_training, segmentation_task_predict
 from .train import SegTrainer, bucket_ranges, allreduce_buckets, shard_indices
 from .data_feed import TileFeed, draw_d4
-from . import metrics, tasks_utils, writer, zone_detect
+from . import checkpoint, metrics, tasks_utils, writer, zone_detect
 
 __all__ = ["Unet", "create_model", "FLAIR_ModelFactory", "MetadataMLP", "FusedCrossEntropyLoss",
            "MulticlassJaccardIndex", "MeanMetric", "segmentation_task_training", "segmentation_task_predict",
-           "SegTrainer", "bucket_ranges", "allreduce_buckets", "shard_indices", "TileFeed", "draw_d4", "metrics", "tasks_utils",
+           "SegTrainer", "bucket_ranges", "allreduce_buckets", "shard_indices", "TileFeed", "draw_d4", "checkpoint", "metrics", "tasks_utils",
            "writer", "zone_detect"]
