@@ -148,7 +148,27 @@ int flair_feed_tiles(const uint8_t* img_u8, const uint8_t* msk_raw, const uint8_
 }
 int flair_detect_convert(const float* logits_nchw, int B, int C, int S, int margin, int output_type, void* out, void* stream) {
   if (!logits_nchw || !out) return -1;
-  return detect_convert(logits_nchw, B, C, S, margin, output_type, out, (hipStream_t)stream);
+  return detect_convert(logits_nchw, B, C, S, margin, output_type, out, nullptr, 0, 0, (hipStream_t)stream);
+}
+int flair_detect_stitch(const float* logits_nchw, int B, int C, int S, int margin, int output_type, const int32_t* tiles,
+                        void* raster_out, int raster_h, int raster_w, void* stream) {
+  if (!logits_nchw || !raster_out || !tiles) return -1;
+  return detect_convert(logits_nchw, B, C, S, margin, output_type, raster_out, tiles, raster_h, raster_w, (hipStream_t)stream);
+}
+int flair_gather_tiles(const uint8_t* raster_u8, int bands, int raster_h, int raster_w, const int32_t* tiles, int B, int S,
+                       const int* channels, int n_channels, int norm_type, const double* means, const double* stds,
+                       float* img_out, void* stream) {
+  if (!raster_u8 || !tiles || !channels || !img_out) return -1;
+  if (n_channels < 1 || n_channels > FeedArgs::MAXCH) return -2;
+  if (norm_type == 2 && (!means || !stds)) return -1;
+  FeedArgs a{};
+  a.img = raster_u8; a.out = img_out; a.B = B; a.Cb = bands; a.Cout = n_channels; a.H = S; a.W = S; a.mode = norm_type;
+  for (int c = 0; c < n_channels; ++c) {
+    a.band[c] = channels[c] - 1;
+    a.mean[c] = norm_type == 2 ? means[c] : 0.0;
+    a.stdv[c] = norm_type == 2 ? stds[c] : 1.0;
+  }
+  return gather_tiles(a, tiles, raster_h, raster_w, (hipStream_t)stream);
 }
 int flair_confmat_masks(const uint8_t* truth_raw, const uint8_t* pred, int64_t n, int C, int truth_offset, int64_t* confmat,
                         void* stream) {

@@ -77,9 +77,41 @@ __global__ __launch_bounds__(256) void feed_tiles_kernel(FeedArgs a) {
   }
 }
 
+// zone_detect Sliced_Dataset.__getitem__ (src/zone_detect/dataset.py:90-113) for a batch of windows of ONE raster held
+// in HBM: boundless read (pixels outside the raster are 0 BEFORE normalisation), band selection, normalisation.
+__global__ __launch_bounds__(256) void gather_tiles_kernel(FeedArgs a, const int* __restrict__ tiles, int Hr, int Wr) {
+  const int S = a.W, S4 = S / 4;
+  const long per_img = (long)S * S4, total = per_img * a.B;
+  const long plane = (long)Hr * Wr;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(t / per_img);
+    const long r = t - (long)b * per_img;
+    const int i = (int)(r / S4), j0 = (int)(r - (long)i * S4) * 4;
+    const int x0 = tiles[b * 6 + 0], y0 = tiles[b * 6 + 1];
+    const int y = y0 + i;
+    const bool yin = (unsigned)y < (unsigned)Hr;
+    for (int c = 0; c < a.Cout; ++c) {
+      const unsigned char* p = a.img + (long)a.band[c] * plane + (long)y * Wr;
+      const double m = a.mean[c], sd = a.stdv[c];
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = x0 + j0 + e;
+        const unsigned char v = (yin && (unsigned)x < (unsigned)Wr) ? p[x] : (unsigned char)0;
+        o[e] = norm_byte(a.mode, v, m, sd);
+      }
+      *reinterpret_cast<float4*>(a.out + ((long)b * a.Cout + c) * S * S + (long)i * S + j0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 // one thread per kept pixel; logits NCHW fp32, so a wave reads 256 contiguous bytes per class plane
+// tiles == null: out is the per-tile (B, 2 | C, K, K) result.  Otherwise out is the whole (2 | C, Hr, Wr) output raster
+// and tile b = {x0, y0, wx0, wx1, wy0, wy1}: its pixel (i, j) lands at (y0 + i, x0 + j) if inside the write window
+// (the part of its margin-cropped centre that no later tile of the slicing job overwrites).
 __global__ __launch_bounds__(256) void detect_convert_kernel(const float* __restrict__ logits, int B, int C, int S, int margin,
-                                                             int mode, void* __restrict__ out) {
+                                                             int mode, void* __restrict__ out, const int* __restrict__ tiles,
+                                                             int Hr, int Wr) {
   const int K = S - 2 * margin;
   const long KK = (long)K * K, SS = (long)S * S, total = KK * B;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -87,6 +119,15 @@ __global__ __launch_bounds__(256) void detect_convert_kernel(const float* __rest
     const long r = t - (long)b * KK;
     const int i = (int)(r / K), j = (int)(r - (long)i * K);
     const float* p = logits + (long)b * C * SS + (long)(i + margin) * S + (j + margin);
+    long obase = (long)b * (mode == 0 ? 2 : C) * KK + r, ostride = KK;
+    if (tiles) {
+      const int* tb = tiles + b * 6;
+      const int gx = tb[0] + margin + j, gy = tb[1] + margin + i;
+      if (gx < tb[2] || gx >= tb[3] || gy < tb[4] || gy >= tb[5]) continue;
+      if ((unsigned)gx >= (unsigned)Wr || (unsigned)gy >= (unsigned)Hr) continue;  // never write outside the raster
+      obase = (long)gy * Wr + gx;
+      ostride = (long)Hr * Wr;
+    }
     float x[MAXC];
     float m = -INFINITY;
 #pragma unroll
@@ -105,14 +146,14 @@ __global__ __launch_bounds__(256) void detect_convert_kernel(const float* __rest
           const float q = x[c] / ssum;
           if (q > pbest) { pbest = q; best = c; }
         }
-      float* o = reinterpret_cast<float*>(out) + (long)b * 2 * KK + r;
+      float* o = reinterpret_cast<float*>(out) + obase;
       o[0] = (float)best;
-      o[KK] = pbest;
+      o[ostride] = pbest;
     } else {  // convert('class_prob'): (p * 255).astype(uint8) — truncation
-      unsigned char* o = reinterpret_cast<unsigned char*>(out) + (long)b * C * KK + r;
+      unsigned char* o = reinterpret_cast<unsigned char*>(out) + obase;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
-        if (c < C) o[(long)c * KK] = (unsigned char)((x[c] / ssum) * 255.f);
+        if (c < C) o[(long)c * ostride] = (unsigned char)((x[c] / ssum) * 255.f);
     }
   }
 }
@@ -168,11 +209,26 @@ int feed_tiles(const FeedArgs& a, hipStream_t s) {
   return 0;
 }
 
-int detect_convert(const float* logits, int B, int C, int S, int margin, int mode, void* out, hipStream_t s) {
+int detect_convert(const float* logits, int B, int C, int S, int margin, int mode, void* out, const int* tiles, int Hr, int Wr,
+                   hipStream_t s) {
   if (C < 1 || C > MAXC || B < 1 || margin < 0 || S - 2 * margin < 1 || mode < 0 || mode > 1) return -2;
+  if (tiles && (Hr < 1 || Wr < 1)) return -2;
   const long K = S - 2 * margin;
-  ProfScope ps("detect_convert", 0.0, (double)B * K * K * (4.0 * C + (mode ? C : 8.0)), s);
-  hipLaunchKernelGGL(detect_convert_kernel, dim3(stream_blocks((long)B * K * K)), dim3(256), 0, s, logits, B, C, S, margin, mode, out);
+  ProfScope ps(tiles ? "detect_stitch" : "detect_convert", 0.0, (double)B * K * K * (4.0 * C + (mode ? C : 8.0)), s);
+  hipLaunchKernelGGL(detect_convert_kernel, dim3(stream_blocks((long)B * K * K)), dim3(256), 0, s, logits, B, C, S, margin, mode, out,
+                     tiles, Hr, Wr);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int gather_tiles(const FeedArgs& a, const int* tiles, int Hr, int Wr, hipStream_t s) {
+  if (a.B < 1 || a.H != a.W || a.W < 4 || (a.W & 3) || a.Cout < 1 || a.Cout > FeedArgs::MAXCH || a.mode < 0 || a.mode > 2) return -2;
+  if (!a.img || !a.out || !tiles || Hr < 1 || Wr < 1) return -1;
+  for (int c = 0; c < a.Cout; ++c)
+    if (a.band[c] < 0 || a.band[c] >= a.Cb) return -2;
+  const long px = (long)a.B * a.H * a.W;
+  ProfScope ps("gather_tiles", 0.0, (double)px * 5.0 * a.Cout, s);
+  hipLaunchKernelGGL(gather_tiles_kernel, dim3(stream_blocks(px / 4)), dim3(256), 0, s, a, tiles, Hr, Wr);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }

@@ -90,7 +90,9 @@ struct FeedArgs {
   double mean[MAXCH], stdv[MAXCH];
 };
 int feed_tiles(const FeedArgs& a, hipStream_t s);
-int detect_convert(const float* logits, int B, int C, int S, int margin, int mode, void* out, hipStream_t s);
+int gather_tiles(const FeedArgs& a, const int* tiles, int Hr, int Wr, hipStream_t s);  // a.img: one (Cb, Hr, Wr) raster
+int detect_convert(const float* logits, int B, int C, int S, int margin, int mode, void* out, const int* tiles, int Hr, int Wr,
+                   hipStream_t s);
 int confmat_masks(const unsigned char* truth, const unsigned char* pred, long n, int C, int truth_offset, long long* confmat,
                   hipStream_t s);
 

@@ -48,6 +48,9 @@ PROTOTYPES = {
     "flair_feed_tiles": (i32, [vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), i32, i32, C.POINTER(C.c_double),
                                C.POINTER(C.c_double), i32, vp, vp, vp]),
     "flair_detect_convert": (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
+    "flair_gather_tiles": (i32, [vp, i32, i32, i32, vp, i32, i32, C.POINTER(i32), i32, i32, C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), vp, vp]),
+    "flair_detect_stitch": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
     "flair_sgd_step": (i32, [vp, vp, i64, f32, vp]),
     "flair_add_rowvec_nchw": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "flair_conv2d_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32]),

@@ -54,3 +54,109 @@ def inference(device, model, use_gpu: bool, config: dict, samples: dict, fused: 
             predictions = torch.softmax(logits, dim=1)
     indices = samples["index"].cpu().numpy()
     return predictions.cpu().numpy(), indices
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Default pipeline (exact clipping, default-sized tiling) over one raster resident in HBM — main.py:386-428.
+
+def get_stride(config: dict) -> list:
+    """src/zone_detect/test/tiles.py:4-15."""
+    img_size = config["img_pixels_detection"]
+    if not config.get("overlap_strat"):
+        return [int(img_size - 2 * config["margin"])]
+    return [int(i * img_size) for i in config["strategies"]["tiling"]["stride_range"]]
+
+
+def _axis_origins(extent: int, patch: int, margin: int, step: int) -> list:
+    """Window origins along one axis as slice_extent lays them out (slicing_job.py:52-67): start one margin before the
+    raster, advance by ``step``, pull a window that would end past extent + margin back to end exactly there;
+    repeats are dropped (slicing_job.py:86-95)."""
+    out = []
+    for o in range(-margin, extent + margin, step):
+        if o + patch > extent + margin:
+            o = extent + margin - patch
+        if o not in out:
+            out.append(o)
+    return out
+
+
+def tile_grid(img_size, patch_size: int, margin: int, stride: int | None = None):
+    """Pixel-space slicing job.  img_size = (width, height).  Returns an (n, 6) int32 array of
+    {x0, y0, wx0, wx1, wy0, wy1} in the job's order (columns outer, rows inner, rows counted from the BOTTOM of the
+    raster like the reference's geographic Y axis): window origin (top-left, image coordinates) and the output
+    rectangle the window owns once every later window of the job has been written over it."""
+    import numpy as np
+    W, H = int(img_size[0]), int(img_size[1])
+    K = patch_size - 2 * margin
+    step = int(stride) if stride else K
+    if K < 1 or W < K or H < K:
+        raise ValueError("raster smaller than the margin-cropped patch")
+    xs = _axis_origins(W, patch_size, margin, step)
+    ys = _axis_origins(H, patch_size, margin, step)  # distance of the window's bottom edge from the raster's bottom edge
+
+    def owned(origins, extent):
+        lo = [o + margin for o in origins]
+        hi = [min(o + patch_size - margin, extent) for o in origins]
+        return [(lo[i], min(hi[i], lo[i + 1]) if i + 1 < len(origins) else hi[i]) for i in range(len(origins))]
+
+    ox, oy = owned(xs, W), owned(ys, H)
+    rows = []
+    for i, x in enumerate(xs):
+        for j, yb in enumerate(ys):
+            rows.append((x, H - (yb + patch_size), ox[i][0], ox[i][1], H - oy[j][1], H - oy[j][0]))
+    return np.asarray(rows, dtype=np.int32)
+
+
+class ZoneDetector:
+    """``model`` over a whole raster: windows are cut, normalised, inferred, converted and stitched on the device; the
+    raster goes up once as stored bytes and the result comes down once."""
+
+    def __init__(self, model, config: dict):
+        import ctypes as C
+        self.model = model
+        self.S = int(config["img_pixels_detection"])
+        self.margin = int(config["margin"])
+        self.output_type = config["output_type"]
+        if self.output_type not in OUTPUT_TYPES:
+            raise ValueError("The output type has not been interpreted.")
+        if config.get("overlap_strat"):
+            raise NotImplementedError("overlap strategies ('average', 'average_weights', 'max') are not built yet")
+        self.stride = get_stride(config)[0]
+        self.batch_size = int(config.get("batch_size", 4))
+        self.channels = [int(c) for c in config["channels"]]
+        norma = config["norma_task"][0]
+        self.norm_type = norma["norm_type"] if norma["norm_type"] in ("custom", "scaling") else "scaling"
+        means, stds = norma.get("norm_means", []), norma.get("norm_stds", [])
+        if self.norm_type == "custom" and len(means) != len(stds):
+            self.norm_type = "scaling"  # dataset.py:77-81
+        n = len(self.channels)
+        self._ch = (C.c_int * n)(*self.channels)
+        self._means = (C.c_double * n)(*[float(m) for m in means[:n]]) if self.norm_type == "custom" else None
+        self._stds = (C.c_double * n)(*[float(s) for s in stds[:n]]) if self.norm_type == "custom" else None
+        self.n_classes = int(config["n_classes"])
+
+    @torch.no_grad()
+    def run(self, raster_u8: torch.Tensor) -> torch.Tensor:
+        if not raster_u8.is_cuda or raster_u8.dtype != torch.uint8 or raster_u8.dim() != 3:
+            raise RuntimeError("raster must be a (bands, H, W) uint8 tensor on the HIP device")
+        raster_u8 = raster_u8.contiguous()
+        bands, Hr, Wr = raster_u8.shape
+        dev = raster_u8.device
+        grid = torch.from_numpy(tile_grid((Wr, Hr), self.S, self.margin, self.stride)).to(dev)
+        mode = OUTPUT_TYPES[self.output_type]
+        out = (torch.zeros(2, Hr, Wr, dtype=torch.float32, device=dev) if mode == 0
+               else torch.zeros(self.n_classes, Hr, Wr, dtype=torch.uint8, device=dev))
+        from .data_feed import NORM_CODES
+        for b0 in range(0, grid.shape[0], self.batch_size):
+            tiles = grid[b0:b0 + self.batch_size].contiguous()
+            B = tiles.shape[0]
+            imgs = torch.empty(B, len(self.channels), self.S, self.S, dtype=torch.float32, device=dev)
+            L.check(L.lib().flair_gather_tiles(L.ptr(raster_u8), bands, Hr, Wr, L.ptr(tiles), B, self.S, self._ch,
+                                               len(self.channels), NORM_CODES[self.norm_type], self._means, self._stds,
+                                               L.ptr(imgs), L.stream()), "flair_gather_tiles")
+            logits = self.model(imgs).float().contiguous()
+            if logits.shape[1] != self.n_classes:
+                raise RuntimeError(f"model returned {logits.shape[1]} classes, config says {self.n_classes}")
+            L.check(L.lib().flair_detect_stitch(L.ptr(logits), B, self.n_classes, self.S, self.margin, mode, L.ptr(tiles),
+                                                L.ptr(out), Hr, Wr, L.stream()), "flair_detect_stitch")
+        return out

@@ -127,6 +127,19 @@ int flair_feed_tiles(const uint8_t* img_u8, const uint8_t* msk_raw, const uint8_
  * output_type 0 'argmax': out fp32 (B, 2, S-2m, S-2m) = [first argmax, max probability];
  * output_type 1 'class_prob': out uint8 (B, C, S-2m, S-2m) = trunc(p * 255). */
 int flair_detect_convert(const float* logits_nchw, int B, int C, int S, int margin, int output_type, void* out, void* stream);
+/* Sliding-window detection over ONE raster resident in HBM (zone_detect default pipeline, src/zone_detect/main.py:386-428).
+ * tiles (device, B x 6 int32): {x0, y0, wx0, wx1, wy0, wy1} per window — top-left pixel of the S x S window in raster
+ * coordinates (may lie outside: Sliced_Dataset reads boundless, src/zone_detect/dataset.py:96-103, so missing pixels are 0
+ * before normalisation) and the raster rectangle [wx0,wx1) x [wy0,wy1) this window owns in the output (its margin-cropped
+ * centre minus what later windows of the slicing job overwrite; stitching 'exact-clipping', compare.py:69-82).
+ * flair_gather_tiles: the dataset's read + normalization (dataset.py:66-88,90-113) -> img_out fp32 (B, n_channels, S, S).
+ * flair_detect_stitch: softmax + crop + convert as flair_detect_convert, written straight into raster_out
+ *   ((2, raster_h, raster_w) fp32 for 'argmax', (C, raster_h, raster_w) uint8 for 'class_prob'). */
+int flair_gather_tiles(const uint8_t* raster_u8, int bands, int raster_h, int raster_w, const int32_t* tiles, int B, int S,
+                       const int* channels, int n_channels, int norm_type, const double* means, const double* stds,
+                       float* img_out, void* stream);
+int flair_detect_stitch(const float* logits_nchw, int B, int C, int S, int margin, int output_type, const int32_t* tiles,
+                        void* raster_out, int raster_h, int raster_w, void* stream);
 
 int flair_sgd_step(float* params, const float* grads, int64_t n, float lr, void* stream);
 /* feats[-1] += x_enc.unsqueeze(1).unsqueeze(-1).repeat(1,512,1,16) — model.py:59-60: x (N,C,H,W) += v (N,H). */

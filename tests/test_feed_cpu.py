@@ -124,3 +124,28 @@ def test_d4_draws_and_feed_refuses_host_tensors():
         DF.TileFeed(norm_type="minmax")
     with pytest.raises(SystemExit):
         DF.TileFeed(channels=[1, 2], norm_type="custom", means=[1.0], stds=[1.0, 2.0])
+
+
+@pytest.mark.parametrize("W,H,P,m", [(200, 168, 64, 8), (512, 512, 512, 128), (1000, 700, 512, 128), (48, 48, 64, 8), (300, 301, 64, 0),
+                                     (2048, 1536, 512, 128)])
+def test_zone_detect_tile_grid_owns_each_pixel_once_like_sequential_writes(W, H, P, m):
+    """The device stitch writes every window in one launch; its ownership rectangles must reproduce the result of the
+    reference's sequential window writes (later windows overwrite earlier ones, main.py:404-421)."""
+    from flair_amd.zone_detect import get_stride, tile_grid
+    from oracle.zone_detect import slice_extent_np
+    assert get_stride({"img_pixels_detection": P, "margin": m}) == [P - 2 * m]
+    assert get_stride({"img_pixels_detection": 512, "margin": 128, "overlap_strat": True,
+                       "strategies": {"tiling": {"stride_range": [0.25, 0.5]}}}) == [128, 256]
+    grid, rows = tile_grid((W, H), P, m), slice_extent_np(W, H, P, m)
+    assert len(grid) == len(rows)
+    last = np.full((H, W), -1)
+    mine = np.full((H, W), -1)
+    count = np.zeros((H, W), int)
+    for t, (g, r) in enumerate(zip(grid, rows)):
+        assert g[0] == round(r["x"]) and g[1] == H - round(r["y"]) - P
+        last[H - round(r["top"]):H - round(r["bottom"]), round(r["left"]):round(r["right"])] = t
+        mine[g[4]:g[5], g[2]:g[3]] = t
+        count[g[4]:g[5], g[2]:g[3]] += 1
+    assert (count == 1).all() and (mine == last).all()
+    with pytest.raises(ValueError):
+        tile_grid((P - 2 * m - 1, H), P, m)

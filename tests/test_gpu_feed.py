@@ -316,3 +316,57 @@ def test_config1_plumbing_on_synthetic_tiles(dev, tmp_path):
     saved = json.load(open(tmp_path / "out" / "metrics" / "metrics.json"))
     assert list(saved) == list(out) and len(saved["per_class_iou"]) == C
     assert 0 <= saved["Avg_metrics"][0] <= 100
+
+
+def test_zone_detector_whole_raster_vs_oracle(dev):
+    """Default zone_detect pipeline on a raster that is not a multiple of the stride (edge windows pulled back,
+    boundless reads outside the raster): device gather -> HIP U-Net -> fused convert + stitch vs the sequential CPU
+    restatement (oracle/zone_detect.py)."""
+    import flair_amd
+    from flair_amd.zone_detect import ZoneDetector
+    from oracle import unet_resnet34 as om
+    from oracle import zone_detect as oz
+    C = 19
+    ref = om.seeded_model(5, C, 6).eval()
+    hip = flair_amd.create_model("unet", "resnet34", encoder_weights=None, in_channels=5, classes=C, compute_dtype="f32")
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip = hip.to(dev).eval()
+    rng = np.random.default_rng(12)
+    raster = rng.integers(0, 256, size=(5, 168, 200), dtype=np.uint8)
+    cfg = {"img_pixels_detection": 64, "margin": 8, "output_type": "argmax", "n_classes": C, "batch_size": 4,
+           "channels": [1, 2, 3, 4, 5], "norma_task": [{"norm_type": "custom", "norm_means": MEANS, "norm_stds": STDS}]}
+    want = oz.detect_raster_np(ref, raster, cfg)
+    got = ZoneDetector(hip, cfg).run(torch.from_numpy(raster).to(dev)).cpu().numpy()
+    assert got.shape == want.shape == (2, 168, 200) and got.dtype == np.float32
+    assert (got[0] != want[0]).mean() < 2e-3  # fp32 logits agree to ~1e-4; only near-ties may flip
+    assert np.abs(got[1] - want[1]).max() < 2e-3
+    cfg2 = dict(cfg, output_type="class_prob", channels=[3, 1, 5, 2, 4], batch_size=7)
+    want = oz.detect_raster_np(ref, raster, cfg2)
+    got = ZoneDetector(hip, cfg2).run(torch.from_numpy(raster).to(dev)).cpu().numpy()
+    assert got.shape == (C, 168, 200) and got.dtype == np.uint8
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    with pytest.raises(NotImplementedError):
+        ZoneDetector(hip, dict(cfg, overlap_strat=True, strategies={"tiling": {"stride_range": [0.5]}}))
+    with pytest.raises(RuntimeError):
+        ZoneDetector(hip, cfg).run(torch.from_numpy(raster))
+
+
+def test_gather_tiles_boundless_and_normalised(dev):
+    """The window read alone, bit-exact: zero fill outside the raster happens BEFORE normalisation."""
+    import ctypes as C
+    from flair_amd import _lib as L
+    from oracle import data_feed as F
+    from oracle import zone_detect as oz
+    rng = np.random.default_rng(2)
+    raster = rng.integers(0, 256, size=(5, 100, 90), dtype=np.uint8)
+    S = 32
+    origins = [(-8, -8), (70, 80), (0, 0), (-31, 99), (58, 68)]
+    tiles = torch.tensor([[x, y, 0, 0, 0, 0] for x, y in origins], dtype=torch.int32, device=dev)
+    rd = torch.from_numpy(raster).to(dev)
+    ch = [2, 5, 1]
+    out = torch.empty(len(origins), 3, S, S, device=dev)
+    L.check(L.lib().flair_gather_tiles(L.ptr(rd), 5, 100, 90, L.ptr(tiles), len(origins), S, (C.c_int * 3)(*ch), 3, 2,
+                                       (C.c_double * 3)(*MEANS[:3]), (C.c_double * 3)(*STDS[:3]), L.ptr(out), L.stream()))
+    for b, (x, y) in enumerate(origins):
+        win = oz.read_window_np(raster, ch, float(x), float(100 - y - S), S)
+        assert np.array_equal(out[b].cpu().numpy(), F.norm_np(win, "custom", MEANS[:3], STDS[:3])), (x, y)
