@@ -21,7 +21,8 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TW = 16, TH = 8, HW_ = TW + 2, HH = TH + 2, HPIX = HW_ * HH, TPIX = TW * TH;  // 180 halo / 128 tile pixels
-constexpr int NT = 512;
+constexpr int NT = 512;   // 8 waves: 4 (output-channel groups) x 2 (input-channel halves) at 128 output channels per workgroup;
+                          // 2 x 2 x 2 (tile-row halves, each with its own slab) at 64
 
 template <typename T> struct BFrag;
 template <> struct BFrag<bf16_t> {
@@ -71,27 +72,34 @@ struct WgBigArgs {
   int Kg, ntiles;
 };
 
-template <typename T>
+// KG = 1: 16*CH output channels per workgroup (256 B of dY per pixel), waves 4 x 2.
+// KG = 2:  8*CH output channels per workgroup (128 B per pixel), waves 2 x 2 x 2: the two wave groups take the upper /
+//          lower half of every tile's rows and fold their sums through LDS at the end (the 64-output-channel layers).
+template <typename T, int KG>
 struct WgBigCfg {
   static constexpr int CH = Elem<T>::CH;
   static constexpr int CK = 8 * CH;        // input channels per workgroup: 128 B per pixel
-  static constexpr int CO = 16 * CH;       // output channels per workgroup: 256 B per pixel
-  static constexpr int XSTRIDE = 128 + 16, DSTRIDE = 256 + 16;
+  static constexpr int CO = 16 * CH / KG;  // output channels per workgroup
+  static constexpr int DCH = 16 / KG;      // 16-byte chunks of dY per pixel
+  static constexpr int XSTRIDE = 128 + 16, DSTRIDE = 256 / KG + 16;
   static constexpr int XBYTES = HPIX * XSTRIDE, DBYTES = TPIX * DSTRIDE;
   static constexpr int STAGE = XBYTES + DBYTES;
   static constexpr int SMEM = 2 * STAGE;
-  static constexpr int COT = CO / 4 / 16, CIT = CK / 2 / 16;   // per-wave 16x16 blocks: bf16 2 x 2, f32 1 x 1
-  static constexpr int XITEMS = (HPIX * 8 + NT - 1) / NT;      // 3
-  static constexpr int DITEMS = (TPIX * 16) / NT;              // 4
+  static constexpr int WK = 4 / KG;                               // output-channel wave groups
+  static constexpr int COT = CO / WK / 16, CIT = CK / 2 / 16;     // per-wave 16x16 blocks: bf16 2 x 2, f32 1 x 1
+  static constexpr int XITEMS = (HPIX * 8 + NT - 1) / NT;         // 3
+  static constexpr int DITEMS = (TPIX * DCH) / NT;                // 4 | 2
 };
 
-template <typename T>
+template <typename T, int KG>
 __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
-  using Cfg = WgBigCfg<T>;
-  constexpr int CH = Cfg::CH, CK = Cfg::CK, CO = Cfg::CO, COT = Cfg::COT, CIT = Cfg::CIT;
+  using Cfg = WgBigCfg<T, KG>;
+  constexpr int CH = Cfg::CH, CK = Cfg::CK, CO = Cfg::CO, COT = Cfg::COT, CIT = Cfg::CIT, DCH = Cfg::DCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wk = wave & 3, wc = wave >> 2;   // output-channel group (of 4), input-channel half (of 2)
+  // output-channel group, input-channel half (of 2), tile-row half
+  const int wk = wave % Cfg::WK, wc = (wave / Cfg::WK) & 1, kg = wave / (2 * Cfg::WK);
+  constexpr int YROWS = TH / KG;
   const int H = a.H, W = a.W;
   const int tiles_x = W / TW, tiles_y = H / TH;
   const int cbase = blockIdx.y * CK, kbase = blockIdx.z * CO;
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
 #pragma unroll
     for (int k = 0; k < Cfg::DITEMS; ++k) {
       const int it = t + NT * k;
-      const int px = it >> 4, ch = it & 15;
+      const int px = it / DCH, ch = it % DCH;
       const int py = px / TW, pxx = px - py * TW;
       const unsigned off = (unsigned)(((n * H + y0 + py) * W + x0p + pxx) * a.dy_ld + kbase + ch * CH);
       dr[k] = *reinterpret_cast<const u32x4*>(dy + (tok ? off : 0u));
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
 #pragma unroll
     for (int k = 0; k < Cfg::DITEMS; ++k) {
       const int it = t + NT * k;
-      *reinterpret_cast<u32x4*>(dyt + (it >> 4) * Cfg::DSTRIDE + (it & 15) * 16) = dr[k];
+      *reinterpret_cast<u32x4*>(dyt + (it / DCH) * Cfg::DSTRIDE + (it % DCH) * 16) = dr[k];
     }
   };
 
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
         return r;
       };
 #pragma unroll 1
-      for (int y = 0; y < TH; y += 2) {
+      for (int y = kg * YROWS; y < (kg + 1) * YROWS; y += 2) {
         u32x4 af[COT];
 #pragma unroll
         for (int co = 0; co < COT; ++co)
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
       }
     } else {
 #pragma unroll 1
-      for (int y = 0; y < TH; ++y) {   // f32: K step = 16 pixels = one tile row
+      for (int y = kg * YROWS; y < (kg + 1) * YROWS; ++y) {   // f32: K step = 16 pixels = one tile row
         u32x4 af[COT];
 #pragma unroll
         for (int co = 0; co < COT; ++co)
@@ -223,7 +231,35 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
     __syncthreads();
   }
 
-  // every wave owns a disjoint block of the gradient: write the slab directly
+  if constexpr (KG == 2) {
+    // fold the lower tile-row half's sums into the upper half's through LDS (the stages are free now), one
+    // output-channel block at a time: [register][lane] words, conflict-free
+    static_assert(COT * CIT * 9 * 4 * 64 * 4 * 4 / COT <= Cfg::SMEM, "reduction scratch exceeds the staging LDS");
+    float* red = reinterpret_cast<float*>(smem) + (wave & 3) * (CIT * 9 * 4) * 64;
+#pragma unroll
+    for (int co = 0; co < COT; ++co) {
+      __syncthreads();
+      if (kg == 1) {
+#pragma unroll
+        for (int ci = 0; ci < CIT; ++ci)
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[((ci * 9 + tp) * 4 + e) * 64 + lane] = acc[co][ci][tp][e];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int ci = 0; ci < CIT; ++ci)
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[co][ci][tp][e] += red[((ci * 9 + tp) * 4 + e) * 64 + lane];
+      }
+    }
+    if (kg == 1) return;
+  }
+  // every (remaining) wave owns a disjoint block of the gradient: write the slab directly
   const int Cin = a.C0 + a.C1;
   float* __restrict__ part = a.partial + (long)blockIdx.x * a.Cout * a.Kg;
   const int lr = lane & 15, lq = lane >> 4;
@@ -243,9 +279,13 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
 
 }  // namespace
 
-static bool wg_big_geom(int dtype, const WgradArgs& a, int& nsplit) {
-  const int ck = dtype == DT_F32 ? 32 : 64, co = dtype == DT_F32 ? 64 : 128;
+// kg = 1: 128 (f32: 64) output channels per workgroup; kg = 2: 64 (32), two slabs per workgroup
+static bool wg_big_geom(int dtype, const WgradArgs& a, int& nsplit, int& kg) {
+  const int ck = dtype == DT_F32 ? 32 : 64;
+  int co = dtype == DT_F32 ? 64 : 128;
   const int Cin = a.C0 + a.C1;
+  kg = 1;
+  if (a.Cout % co) { co /= 2; kg = 2; }
   if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1) return false;
   if (a.Hout != a.Hin || a.Wout != a.Win || (a.Hin % TH) || (a.Win % TW)) return false;
   if ((Cin % ck) || (a.C0 % ck) || (a.Cout % co) || a.dy_ld != a.Cout) return false;
@@ -259,20 +299,20 @@ static bool wg_big_geom(int dtype, const WgradArgs& a, int& nsplit) {
 }
 
 bool wgrad_big_applicable(int dtype, const WgradArgs& a) {
-  int ns;
-  return wg_big_geom(dtype, a, ns);
+  int ns, kg;
+  return wg_big_geom(dtype, a, ns, kg);
 }
 
 size_t wgrad_big_workspace_bytes(int dtype, const WgradArgs& a) {
-  int ns;
-  if (!wg_big_geom(dtype, a, ns)) return 0;
+  int ns, kg;
+  if (!wg_big_geom(dtype, a, ns, kg)) return 0;
   return (size_t)ns * a.Cout * 9 * (a.C0 + a.C1) * sizeof(float);
 }
 
-template <typename T>
+template <typename T, int KG>
 static int launch_big_t(const WgBigArgs& h, int nsplit, int Cin, hipStream_t s) {
-  using Cfg = WgBigCfg<T>;
-  auto kern = wgrad3x3_big_kernel<T>;
+  using Cfg = WgBigCfg<T, KG>;
+  auto kern = wgrad3x3_big_kernel<T, KG>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
@@ -281,7 +321,7 @@ static int launch_big_t(const WgBigArgs& h, int nsplit, int Cin, hipStream_t s) 
   }
   dim3 grid(nsplit, Cin / Cfg::CK, h.Cout / Cfg::CO);
   const double M = (double)h.N * h.H * h.W;
-  ProfScope ps(sizeof(T) == 2 ? "wgrad3x3_big_bf16" : "wgrad3x3_big_f32", 2.0 * M * h.Cout * 9.0 * Cin,
+  ProfScope ps(sizeof(T) == 2 ? (KG == 1 ? "wgrad3x3_big_bf16" : "wgrad3x3_big_bf16_co64") : "wgrad3x3_big_f32", 2.0 * M * h.Cout * 9.0 * Cin,
                (M * h.dy_ld + M * (h.C0 / (h.up0 ? 4.0 : 1.0) + h.C1)) * sizeof(T), s);
   hipLaunchKernelGGL(kern, grid, dim3(NT), Cfg::SMEM, s, h);
   FLAIR_CHECK_LAUNCH();
@@ -289,14 +329,16 @@ static int launch_big_t(const WgBigArgs& h, int nsplit, int Cin, hipStream_t s) 
 }
 
 int launch_wgrad_big(int dtype, const WgradArgs& a, hipStream_t s) {
-  int nsplit;
-  if (!wg_big_geom(dtype, a, nsplit)) return -2;
+  int nsplit, kg;
+  if (!wg_big_geom(dtype, a, nsplit, kg)) return -2;
   const int Cin = a.C0 + a.C1;
   WgBigArgs h;
   h.x0 = a.x0; h.x1 = a.x1; h.C0 = a.C0; h.C1 = a.C1; h.up0 = a.up0; h.N = a.N; h.H = a.Hin; h.W = a.Win;
   h.dy = a.dy; h.dy_ld = a.dy_ld; h.Cout = a.Cout; h.partial = a.partial; h.Kg = 9 * Cin;
   h.ntiles = (int)((long)a.N * a.Hin * a.Win / TPIX);
-  const int rc = dtype == DT_F32 ? launch_big_t<float>(h, nsplit, Cin, s) : launch_big_t<bf16_t>(h, nsplit, Cin, s);
+  int rc;
+  if (dtype == DT_F32) rc = kg == 1 ? launch_big_t<float, 1>(h, nsplit, Cin, s) : launch_big_t<float, 2>(h, nsplit, Cin, s);
+  else rc = kg == 1 ? launch_big_t<bf16_t, 1>(h, nsplit, Cin, s) : launch_big_t<bf16_t, 2>(h, nsplit, Cin, s);
   if (rc) return rc;
   launch_wgrad_reduce(a.partial, a.dw, nsplit, a.Cout, a.Cout, 9 * Cin, Cin, a.Cin_real, 3, 3, a.accumulate, s);
   hipError_t e = hipGetLastError();
