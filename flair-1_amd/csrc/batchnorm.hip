@@ -395,12 +395,13 @@ int colsum(int dtype, const void* x, long rows, int ld, int C, float* partial, f
 int bn_backward(int dtype, const void* dout, const void* out, const void* y, const float* mean, const float* invstd,
                 const float* gamma, long rows, int C, float* partial, float* coef /*3*C*/, float* dgamma, float* dbeta,
                 int accumulate_param, void* dy, void* dres, int dres_accumulate, const float* mscale, const float* mshift,
-                hipStream_t s) {
+                int pre_nblk, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C % ch || C / ch > 128) return -2;
-  const int nblk = bn_bwd_blocks(rows);
+  if (pre_nblk > 0 && (out || !mscale)) return -2;  // a producer-side reduction exists for mask-from-y units only
+  const int nblk = pre_nblk > 0 ? pre_nblk : bn_bwd_blocks(rows);
   const long rpb = (rows + nblk - 1) / nblk;
-  {
+  if (pre_nblk <= 0) {
     if (out) { mscale = nullptr; mshift = nullptr; }
     ProfScope ps1("bn_bwd_reduce", 0.0, (double)rows * C * dtype_size(dtype) * (out ? 3 : 2), s);
     if (dtype == DT_F32)
@@ -409,8 +410,8 @@ int bn_backward(int dtype, const void* dout, const void* out, const void* y, con
     else
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)dout,
                          (const bf16_t*)out, (const bf16_t*)y, mean, invstd, partial, rows, C, rpb, mscale, mshift);
+    FLAIR_CHECK_LAUNCH();
   }
-  FLAIR_CHECK_LAUNCH();
   float *k1 = coef, *k2 = coef + C, *k3 = coef + 2 * C;
   {
     ProfScope ps3("bn_bwd_finalize", 0.0, (double)nblk * 2 * C * 4.0, s);

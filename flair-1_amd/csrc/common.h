@@ -106,10 +106,21 @@ struct ConvArgs {
   void* out_skip;
   int out_skip_ld;
   int skip_accumulate;
+  // optional fused first pass of the BatchNorm backward of the unit that PRODUCED this conv's input (halo-tile
+  // kernels only).  `out` (the pooled part when pool_c0 > 0) is then the complete gradient dz w.r.t. that unit's
+  // ReLU output; the epilogue also reads the unit's pre-BN tensor bnr_y (same shape and row stride as `out`) and
+  // leaves  sum(dz*m)  and  sum(dz*m*y),  m = [y*bnr_scale + bnr_shift > 0],  per pixel tile in
+  // bnr_partial[2][bnr_C][gridDim.x] — what bn_bwd_reduce_kernel would compute from HBM.
+  const void* bnr_y;
+  const float* bnr_scale;
+  const float* bnr_shift;
+  float* bnr_partial;
+  int bnr_C;
 };
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s);
 int conv_grid_rows(int dtype, const ConvArgs& a);  // number of row blocks (= partial-stat rows)
+bool conv_mfma_bound(int dtype, const ConvArgs& a);  // true when launch_conv picks the 128-wide halo-GEMM kernel
 
 // Weight gradient: dW[k][(r,s),c] = sum_p dY[p][k] * im2col(X)[p][(r,s),c]; split over pixels.
 struct WgradArgs {

@@ -59,7 +59,9 @@ struct HgCfg {
   static constexpr int BITEMS = (BN * 8 + NT - 1) / NT;
 };
 
-template <typename T, int TW, int TH, int BN, int HB>
+// BNR: instantiate the fused BatchNorm-backward reduction of the epilogue (ConvArgs::bnr_*); kept out of the plain
+// variant so that its register allocation does not pay for it
+template <typename T, int TW, int TH, int BN, int HB, bool BNR>
 __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const ConvArgs a) {  // 64 * (TPIX/64) * (BN/64) threads
   using Cfg = HgCfg<T, TW, TH, BN, HB>;
   constexpr int CH = Cfg::CH, CK = Cfg::CK, HW_ = Cfg::HW_, HPIX = Cfg::HPIX, NT = Cfg::NT, TPIX = Cfg::TPIX;
@@ -255,15 +257,15 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const 
     a.stats[(long)(n0 + t) * gridDim.x + blockIdx.x] = x1;
     a.stats[((long)a.Cout + n0 + t) * gridDim.x + blockIdx.x] = x2;
   }
-  store_tile<T, TW, TPIX, BN, NT, Cfg::CLD>(a, ct, n, y0, x0, n0, t);
+  store_tile<T, TW, TPIX, BN, NT, Cfg::CLD, BNR>(a, ct, n, y0, x0, n0, t);
 }
 
 int g_hg_variant = -1;  // tuning override (FLAIR_HG_VARIANT): 0 = 256 px x 8 waves, 1 = 128 px x 4 waves x 2 WG/CU
 
-template <typename T, int TW, int TH, int BN, int HB>
-int launch_hg_cfg(const ConvArgs& a, hipStream_t s) {
+template <typename T, int TW, int TH, int BN, int HB, bool BNR>
+int launch_hg_cfg_b(const ConvArgs& a, hipStream_t s) {
   using Cfg = HgCfg<T, TW, TH, BN, HB>;
-  auto kern = conv3x3_hg_kernel<T, TW, TH, BN, HB>;
+  auto kern = conv3x3_hg_kernel<T, TW, TH, BN, HB, BNR>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
@@ -282,6 +284,11 @@ int launch_hg_cfg(const ConvArgs& a, hipStream_t s) {
   }
   FLAIR_CHECK_LAUNCH();
   return 0;
+}
+
+template <typename T, int TW, int TH, int BN, int HB>
+int launch_hg_cfg(const ConvArgs& a, hipStream_t s) {
+  return a.bnr_partial ? launch_hg_cfg_b<T, TW, TH, BN, HB, true>(a, s) : launch_hg_cfg_b<T, TW, TH, BN, HB, false>(a, s);
 }
 
 }  // namespace

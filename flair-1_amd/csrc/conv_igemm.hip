@@ -337,6 +337,16 @@ bool conv_tile_epilogue_ok(int dtype, const ConvArgs& a) {
   return false;
 }
 
+bool conv_mfma_bound(int dtype, const ConvArgs& a) {
+  static int mode = -1;  // tuning override FLAIR_BNR: 0 = never fuse, 1 = 128-wide halo-GEMM only, 2 = every halo-GEMM
+  if (mode < 0) {
+    const char* e = getenv("FLAIR_BNR");
+    mode = e ? atoi(e) : 2;
+  }
+  if (mode == 0 || !conv_hg_applicable(dtype, a)) return false;
+  return mode == 2 || (a.Cout % 128) == 0;
+}
+
 int conv_grid_rows(int dtype, const ConvArgs& a) {
   if (conv_hg_applicable(dtype, a)) return conv_hg_grid_rows(dtype, a);
   if (conv_halo_applicable(a)) return conv_halo_grid_rows(a);
@@ -362,6 +372,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
   if (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a)) return -6;
+  if (a.bnr_partial && !(conv_tile_epilogue_ok(dtype, a) && conv_hg_applicable(dtype, a))) return -6;  // halo-GEMM epilogue only
   if (conv_hg_applicable(dtype, a)) return launch_conv_hg(dtype, a, s);  // MFMA-bound 3x3 s1 layers: halo GEMM
   if (conv_halo_applicable(a)) {  // HBM-bound small-channel 3x3 layers: halo-tile direct kernel
     const int ch = dtype == DT_F32 ? 4 : 8;

@@ -54,6 +54,10 @@ struct Unit {  // conv -> BN -> (+ residual) -> ReLU
   bool relu = true;
   int res_unit = -1;   // downsample unit whose BN output is the residual
   Act res;             // identity residual
+  // backward: set when the one consumer of `out` already reduced sum(dz), sum(dz*y) per pixel tile in the epilogue of
+  // its data-gradient kernel (ConvArgs::bnr_*); consumed (and cleared) by unit_backward
+  float* bnr_partial = nullptr;
+  int bnr_nblk = 0;
 };
 
 class UNet {
@@ -120,6 +124,9 @@ class UNet {
   void stage_done(int stage);
 
   struct GradBuf { void* act; void* g; bool init; };
+  // unit whose ReLU output is `a`, if `a` has exactly one consumer and the unit's mask comes from y; else -1
+  int sole_producer(const Act& a) const;
+  void attach_bn_reduce(ConvArgs& a, const Act& target);
   std::vector<GradBuf> gbufs_;
   void* grad_of(const Act& a, bool* accumulate);
   void* grad_peek(const Act& a);

@@ -376,24 +376,63 @@ int UNet::head_forward(const float* params, const float* x_nchw, float* logits_n
 }
 
 // ------------------------------------------------------------------------------------------ backward
+// conv1 of every BasicBlock feeds conv2 only, decoder conv1 feeds conv2 only, decoder conv2 feeds the next block's
+// upsample (or the head) only: for these units the data-gradient kernel of the single consumer writes the COMPLETE dz,
+// so it can also do the first pass of their BatchNorm backward in its epilogue.
+int UNet::sole_producer(const Act& a) const {
+  if (!a.p) return -1;
+  for (int i = 0; i < (int)units_.size(); ++i) {
+    const Unit& u = units_[i];
+    if (u.out.p != a.p) continue;
+    const bool mask_from_y = u.relu && u.res_unit < 0 && !u.res.p;
+    if (!mask_from_y) return -1;
+    int consumers = 0;
+    for (const Unit& v : units_) consumers += (v.in0.p == a.p) + (v.in1.p == a.p) + (v.res.p == a.p);
+    for (int f = 1; f <= 5; ++f) consumers += (f_[f].p == a.p);  // encoder features also feed the decoder
+    if (a.p == dec_out_.p) consumers += 1;                        // the head
+    return consumers == 1 ? i : -1;
+  }
+  return -1;
+}
+
+void UNet::attach_bn_reduce(ConvArgs& a, const Act& target) {
+  const int p = sole_producer(target);
+  if (p < 0) return;
+  Unit& u = units_[p];
+  a.bnr_y = u.y.p; a.bnr_scale = u.scale; a.bnr_shift = u.shift; a.bnr_C = u.y.C;
+  a.bnr_partial = reinterpret_cast<float*>(1);  // provisional, so that the geometry check sees the request
+  // only where the data-gradient kernel is MFMA-bound (the extra read of y hides under it); the small-channel
+  // halo kernels are HBM-bound and gain nothing over the separate streaming reduction
+  if (a.accumulate || u.y.C != a.out_ld || !conv_tile_epilogue_ok(dtype, a) || !conv_mfma_bound(dtype, a)) {
+    a.bnr_y = nullptr; a.bnr_partial = nullptr; a.bnr_scale = a.bnr_shift = nullptr; a.bnr_C = 0;
+    return;
+  }
+  const int nblk = conv_grid_rows(dtype, a);
+  a.bnr_partial = alloc_f((long)nblk * 2 * u.y.C);
+  u.bnr_partial = a.bnr_partial;
+  u.bnr_nblk = nblk;
+}
+
 // Backward of one conv->BN->(+res)->ReLU unit.  dout = gradient w.r.t. u.out (or w.r.t. the BN
 // output when the unit was not materialised).  Produces parameter gradients, optionally the
 // residual-branch gradient dz (dres) and the input gradient (into grad_of(in0) or dx_override).
 void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bool need_dgrad, void* dx_override,
                          bool upcat) {
-  const Unit& u = units_[ui];
+  Unit& u = units_[ui];
   const ConvDesc& c = convs[u.conv];
   const BnDesc& b = bns[u.bn];
   const long rows = u.y.rows();
   void* dy = alloc((size_t)u.y.elems() * dtype_size(dtype));
-  float* partial = alloc_f((long)bn_bwd_blocks(rows) * 2 * b.C);
+  const int pre_nblk = u.bnr_nblk;
+  float* partial = pre_nblk > 0 ? u.bnr_partial : alloc_f((long)bn_bwd_blocks(rows) * 2 * b.C);
+  u.bnr_partial = nullptr; u.bnr_nblk = 0;
   float* coef = alloc_f(3 * b.C);
   // ReLU mask: units without a residual recompute it from y (out > 0 <=> y*scale + shift > 0) and skip
   // reading the activation tensor in both backward passes
   const bool mask_from_y = u.relu && u.res_unit < 0 && !u.res.p;
   RUN(bn_backward(dtype, dout, (u.relu && !mask_from_y) ? u.out.p : nullptr, u.y.p, u.mean, u.invstd, params_ + b.g_off,
                   rows, b.C, partial, coef, grads_ + b.g_off, grads_ + b.b_off, 0, dy, dres, dres_acc ? 1 : 0,
-                  mask_from_y ? u.scale : nullptr, mask_from_y ? u.shift : nullptr, s_));
+                  mask_from_y ? u.scale : nullptr, mask_from_y ? u.shift : nullptr, pre_nblk, s_));
   // weight gradient
   WgradArgs w;
   memset(&w, 0, sizeof(w));
@@ -428,6 +467,7 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
     a.pool_c0 = C0; a.out = dx0; a.out_ld = C0; a.accumulate = acc0 ? 1 : 0;
     a.out_skip = dsk; a.out_skip_ld = C1; a.skip_accumulate = acc1 ? 1 : 0;
     if (conv_tile_epilogue_ok(dtype, a)) {
+      attach_bn_reduce(a, u.in0);   // the pooled half is the whole gradient of the previous block's output
       RUN(launch_conv(dtype, a, s_));
     } else {
       void* dcat = alloc((size_t)u.y.rows() * (C0 + C1) * dtype_size(dtype));
@@ -443,6 +483,7 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
     bool acc = false;
     a.out = grad_of(u.in0, &acc);
     a.accumulate = acc ? 1 : 0;
+    attach_bn_reduce(a, u.in0);
   }
   RUN(launch_conv(dtype, a, s_));
 }
@@ -468,6 +509,7 @@ void UNet::head_bwd_impl(const void* dl) {
   bool acc = false;
   a.out = grad_of(dec_out_, &acc);
   a.out_ld = c.Cin_p; a.accumulate = acc ? 1 : 0;
+  attach_bn_reduce(a, dec_out_);
   RUN(launch_conv(dtype, a, s_));
 }
 
