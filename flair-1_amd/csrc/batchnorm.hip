@@ -21,6 +21,35 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// this thread's share of two rows of tile partials (256 threads per row): 16-byte loads, 8 loads in flight,
+// fp64 accumulation in a fixed order
+__device__ __forceinline__ void column_sums_f64(const float* __restrict__ p1, const float* __restrict__ p2, int nblk,
+                                                double& s1, double& s2) {
+  if ((nblk & 3) == 0) {
+    const float4* q1 = reinterpret_cast<const float4*>(p1);
+    const float4* q2 = reinterpret_cast<const float4*>(p2);
+    const int n4 = nblk >> 2;
+    int b = threadIdx.x;
+    for (; b + 768 < n4; b += 1024) {
+      float4 u[4], v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { u[k] = q1[b + 256 * k]; v[k] = q2[b + 256 * k]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s1 += ((double)u[k].x + (double)u[k].y) + ((double)u[k].z + (double)u[k].w);
+        s2 += ((double)v[k].x + (double)v[k].y) + ((double)v[k].z + (double)v[k].w);
+      }
+    }
+    for (; b < n4; b += 256) {
+      const float4 u = q1[b], v = q2[b];
+      s1 += ((double)u.x + (double)u.y) + ((double)u.z + (double)u.w);
+      s2 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    }
+  } else {
+    for (int b = threadIdx.x; b < nblk; b += 256) { s1 += (double)p1[b]; s2 += (double)p2[b]; }
+  }
+}
+
 // partial [2][C][nblk] -> scale/shift (+ saved mean / invstd, running-stat update); grid = C
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -33,7 +62,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const float* p1 = partial + (long)c * nblk;
   const float* p2 = partial + ((long)C + c) * nblk;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 256) { s1 += (double)p1[b]; s2 += (double)p2[b]; }
+  column_sums_f64(p1, p2, nblk, s1, s2);
   const double a1 = block_sum_f64(s1, sh);
   const double a2 = block_sum_f64(s2, sh);
   if (threadIdx.x == 0) {
@@ -196,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   const float* p1 = partial + (long)c * nblk;
   const float* p2 = partial + ((long)C + c) * nblk;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 256) { s1 += (double)p1[b]; s2 += (double)p2[b]; }
+  column_sums_f64(p1, p2, nblk, s1, s2);
   const double a1 = block_sum_f64(s1, sh);
   const double a2 = (block_sum_f64(s2, sh) - (double)mean[c] * a1) * (double)invstd[c];  // sum dz*xhat
   if (threadIdx.x == 0) {
