@@ -181,6 +181,105 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const float* __restrict__ 
   }
 }
 
+// Same arithmetic, four consecutive pixels per thread: every class plane is read with 16-byte loads (a wave covers
+// 1 KB per plane instead of 256 B) and predictions leave as one 32-bit word.  Needs HW % 4 == 0.
+template <int CM>
+__global__ __launch_bounds__(256) void ce_main4_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ lab8,
+                                                       const float* __restrict__ weight, const float* __restrict__ den,
+                                                       int C, long HW, long npix, float* __restrict__ loss_partial,
+                                                       float* __restrict__ dl_nchw, void* __restrict__ dl_nhwc, int dl_dtype,
+                                                       int dl_ld, unsigned char* __restrict__ preds_u8,
+                                                       long long* __restrict__ preds_i64, long long* __restrict__ confmat) {
+  __shared__ float sh[4];
+  __shared__ unsigned int hist[MAXC * MAXC];
+  if (confmat) {
+    for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0;
+    __syncthreads();
+  }
+  const float inv_den = 1.f / den[0];
+  float acc = 0.f;
+  const long ngroups = npix >> 2;
+  for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (long)gridDim.x * blockDim.x) {
+    const long i = gi << 2;
+    const long n = i / HW, pix = i - n * HW;
+    const float* p = logits + n * C * HW + pix;
+    float4 xv[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c)
+      if (c < C) xv[c] = *reinterpret_cast<const float4*>(p + (long)c * HW);
+    const unsigned int lab4 = *reinterpret_cast<const unsigned int*>(lab8 + i);
+    unsigned int pred4 = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float x[CM];
+      float m = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) { x[c] = reinterpret_cast<const float*>(&xv[c])[q]; m = fmaxf(m, x[c]); }
+      const int y = (lab4 >> (8 * q)) & 0xff;
+      const bool ok = y < C;
+      float xy = 0.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C && c == y) xy = x[c];
+      float ssum = 0.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) { x[c] = expf(x[c] - m); ssum += x[c]; }
+      int pred = 0;
+      float pbest = -1.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) {
+          x[c] = x[c] / ssum;
+          if (x[c] > pbest) { pbest = x[c]; pred = c; }
+        }
+      const float w = ok ? (weight ? weight[y] : 1.f) : 0.f;
+      if (ok) acc += w * (logf(ssum) - (xy - m));
+      pred4 |= (unsigned int)pred << (8 * q);
+      if (confmat && ok) atomicAdd(&hist[y * C + pred], 1u);
+      if (dl_nchw || dl_nhwc) {
+        const float sc = w * inv_den;
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+          if (c < C) x[c] = (x[c] - ((ok && c == y) ? 1.f : 0.f)) * sc;
+        if (dl_nhwc) {
+          float g[MAXC];
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c) g[c] = c < CM ? x[c < CM ? c : 0] : 0.f;
+          if (dl_dtype == DT_F32) store_row<float>((float*)dl_nhwc + (i + q) * dl_ld, g, C, dl_ld);
+          else store_row<bf16_t>((bf16_t*)dl_nhwc + (i + q) * dl_ld, g, C, dl_ld);
+        }
+        if (dl_nchw) {
+#pragma unroll
+          for (int c = 0; c < CM; ++c)
+            if (c < C) reinterpret_cast<float*>(&xv[c])[q] = x[c];
+        }
+      }
+    }
+    if (preds_u8) *reinterpret_cast<unsigned int*>(preds_u8 + i) = pred4;
+    if (preds_i64) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) preds_i64[i + q] = (pred4 >> (8 * q)) & 0xff;
+    }
+    if (dl_nchw) {
+      float* d = dl_nchw + n * C * HW + pix;
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) *reinterpret_cast<float4*>(d + (long)c * HW) = xv[c];
+    }
+  }
+  const float r = block_sum(acc, sh);
+  if (threadIdx.x == 0) loss_partial[blockIdx.x] = r;
+  if (confmat) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += 256) {
+      const unsigned int v = hist[i];
+      if (v) atomicAdd(reinterpret_cast<unsigned long long*>(confmat + i), (unsigned long long)v);
+    }
+  }
+}
+
 int ce_head(const CeArgs& a, hipStream_t s) {
   if (a.C > MAXC || a.C < 1) return -2;
   if (a.dlogits_nhwc && (a.dlogits_ld < a.C || a.dlogits_ld > MAXC || a.dlogits_ld % (a.dlogits_dtype == DT_F32 ? 4 : 8))) return -3;
@@ -198,12 +297,21 @@ int ce_head(const CeArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, s, den_partial, nb, den, (const float*)nullptr);
   FLAIR_CHECK_LAUNCH();
   ProfScope* p2 = new ProfScope("ce_main", 0.0, (double)npix * (4.0 * a.C * (1 + (a.dlogits_nchw ? 1 : 0)) + 2 + (a.dlogits_nhwc ? a.dlogits_ld * dtype_size(a.dlogits_dtype) : 0)), s);
-  hipLaunchKernelGGL(ce_main_kernel, dim3(nb), dim3(256), 0, s, a.logits, lab8, a.weight, den, a.C, HW, npix,
-                     loss_partial, a.dlogits_nchw, a.dlogits_nhwc, a.dlogits_dtype, a.dlogits_ld, a.preds_u8,
-                     a.preds_i64, a.confmat);
+  int nb_main = nb;
+  const bool vec4 = (HW % 4) == 0 && (!a.dlogits_nhwc || a.dlogits_ld <= (a.C <= 16 ? 16 : 32));
+  if (vec4) {
+    nb_main = ce_blocks(npix / 4);
+    auto kern = a.C <= 16 ? ce_main4_kernel<16> : ce_main4_kernel<32>;
+    hipLaunchKernelGGL(kern, dim3(nb_main), dim3(256), 0, s, a.logits, lab8, a.weight, den, a.C, HW, npix, loss_partial,
+                       a.dlogits_nchw, a.dlogits_nhwc, a.dlogits_dtype, a.dlogits_ld, a.preds_u8, a.preds_i64, a.confmat);
+  } else {
+    hipLaunchKernelGGL(ce_main_kernel, dim3(nb), dim3(256), 0, s, a.logits, lab8, a.weight, den, a.C, HW, npix,
+                       loss_partial, a.dlogits_nchw, a.dlogits_nhwc, a.dlogits_dtype, a.dlogits_ld, a.preds_u8,
+                       a.preds_i64, a.confmat);
+  }
   FLAIR_CHECK_LAUNCH();
   delete p2;
-  hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, s, loss_partial, nb, a.loss, den);
+  hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, s, loss_partial, nb_main, a.loss, den);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }
