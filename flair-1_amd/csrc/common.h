@@ -106,6 +106,9 @@ struct ConvArgs {
   void* out_skip;
   int out_skip_ld;
   int skip_accumulate;
+  // optional output sub-sampling (gather-form kernel only): output pixel (ho, wo) is pixel (2*ho + out_oy, 2*wo + out_ox)
+  // of a [N][2*Hout][2*Wout][out_ld] tensor — one parity class of a stride-2 data gradient
+  int out_sub, out_oy, out_ox;
   // optional fused first pass of the BatchNorm backward of the unit that PRODUCED this conv's input (halo-tile
   // kernels only).  `out` (the pooled part when pool_c0 > 0) is then the complete gradient dz w.r.t. that unit's
   // ReLU output; the epilogue also reads the unit's pre-BN tensor bnr_y (same shape and row stride as `out`) and

@@ -247,13 +247,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       const int n = n0 + ch * CH;
       if (m < M && n < a.Cout) {
         uint4 v = *reinterpret_cast<const uint4*>(ct + row * Cfg::CLD + ch * 16);
-        T* dst = out + m * a.out_ld + n;
+        long mo = m;
+        if (a.out_sub) {
+          const int HWo = a.Hout * a.Wout;
+          const int img = (int)(m / HWo), rem = (int)(m - (long)img * HWo);
+          const int ho = rem / a.Wout, wo = rem - ho * a.Wout;
+          mo = ((long)img * 2 * a.Hout + 2 * ho + a.out_oy) * (2 * a.Wout) + 2 * wo + a.out_ox;
+        }
+        T* dst = out + mo * a.out_ld + n;
         if (a.ores || a.orelu) {
           float fa[CH];
           chunk_to_f<T>(v, fa);
           if (a.ores) {
             float fb[CH];
-            chunk_to_f<T>(*reinterpret_cast<const uint4*>((const T*)a.ores + m * a.out_ld + n), fb);
+            chunk_to_f<T>(*reinterpret_cast<const uint4*>((const T*)a.ores + mo * a.out_ld + n), fb);
 #pragma unroll
             for (int e = 0; e < CH; ++e) fa[e] += fb[e];
           }
@@ -371,6 +378,8 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
+  if (a.out_sub && (a.out_nchw || a.stats || a.pool_c0 > 0 || a.bnr_partial || conv_hg_applicable(dtype, a) || conv_halo_applicable(a)))
+    return -6;  // sub-sampled stores exist in the gather-form epilogue only
   if (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a)) return -6;
   if (a.bnr_partial && !(conv_tile_epilogue_ok(dtype, a) && conv_hg_applicable(dtype, a))) return -6;  // halo-GEMM epilogue only
   if (conv_hg_applicable(dtype, a)) return launch_conv_hg(dtype, a, s);  // MFMA-bound 3x3 s1 layers: halo GEMM

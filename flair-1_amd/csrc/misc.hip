@@ -212,13 +212,15 @@ __global__ void pack_weights_all_kernel(const float* __restrict__ params, unsign
   const float* __restrict__ w = params + d.w_off;
   T* __restrict__ dst = reinterpret_cast<T*>(base + d.dst_off);
   const long total = (long)d.rows_pad * d.Kpad;
-  const int RS = d.R * d.S;
+  const int Rc = d.Rc > 0 ? d.Rc : d.R, Sc = d.Rc > 0 ? d.Sc : d.S;
+  const int r0 = d.Rc > 0 ? d.r0 : 0, rstep = d.Rc > 0 ? d.rstep : 1, s0 = d.Rc > 0 ? d.s0 : 0, sstep = d.Rc > 0 ? d.sstep : 1;
+  const int RS = Rc * Sc;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / d.Kpad), kk = (int)(i - (long)row * d.Kpad);
     const int tap = kk / d.Cin_p, c = kk - tap * d.Cin_p;
     float v = 0.f;
     if (tap < RS) {
-      const int r = tap / d.S, q = tap - r * d.S;
+      const int r = r0 + (tap / Sc) * rstep, q = s0 + (tap % Sc) * sstep;
       if (!d.tf) {
         if (row < d.Cout && c < d.Cin) v = w[(((long)row * d.Cin + c) * d.R + r) * d.S + q];
       } else {

@@ -37,9 +37,12 @@ struct PackDesc {
   long w_off;      // float offset of the OIHW master in the flat parameter buffer
   size_t dst_off;  // byte offset of the packed copy from the arena base
   int Cout, Cin, R, S, Cin_p, rows_pad, Kpad, tf;
+  // tap subset of the packed copy: packed tap (ri, si), ri < Rc, si < Sc, is tap (r0 + ri*rstep, s0 + si*sstep) of the
+  // full R x S pack (Rc = 0: all taps).  Used by the parity classes of a stride-2 data gradient.
+  unsigned char r0, rstep, Rc, s0, sstep, Sc, pad_[2];
 };
 struct PackTable {
-  static constexpr int MAX = 48;
+  static constexpr int MAX = 64;
   int n;
   PackDesc d[MAX];
 };

@@ -27,6 +27,11 @@ struct ConvDesc {
   size_t wf = 0, wd = 0;
   int Kg, Kpad, rows_f;   // forward pack
   int Kgd, Kpad_d, rows_d;  // data-gradient pack (rows = Cin_p, K = R*S*Cout_p)
+  // 3x3 stride-2 layers: the data gradient splits by output parity (py, px) into four stride-1 convolutions over dY
+  // with 1, 2, 2 and 4 of the nine taps (class = 2*py + px) — a quarter of the gather-form kernel's MFMA work
+  size_t wd_cls[4] = {0, 0, 0, 0};
+  int Kg_cls[4] = {0, 0, 0, 0}, Kpad_cls[4] = {0, 0, 0, 0};
+  bool parity_dgrad() const { return stride == 2 && R == 3 && S == 3 && pad == 1; }
 };
 
 struct BnDesc {

@@ -149,6 +149,16 @@ void UNet::begin(void* ws, size_t ws_bytes, hipStream_t s, bool dry) {
   for (auto& c : convs) {
     c.wd = top_; alloc((size_t)c.rows_d * c.Kpad_d * dtype_size(dtype));
   }
+  const int kstep = dtype == DT_F32 ? 32 : 64;
+  for (auto& c : convs) {
+    if (!c.parity_dgrad()) continue;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int taps = ((cls >> 1) ? 2 : 1) * ((cls & 1) ? 2 : 1);
+      c.Kg_cls[cls] = taps * c.Cout_p;
+      c.Kpad_cls[cls] = (int)round_up(c.Kg_cls[cls], kstep);
+      c.wd_cls[cls] = top_; alloc((size_t)c.rows_d * c.Kpad_cls[cls] * dtype_size(dtype));
+    }
+  }
 }
 
 // fp32 OIHW masters -> packed T copies, all 47 convolutions in one launch
@@ -159,6 +169,7 @@ void UNet::pack_forward_weights() {
     PackDesc& d = tb.d[tb.n++];
     d.w_off = c.w_off; d.dst_off = c.wf; d.Cout = c.Cout; d.Cin = c.Cin; d.R = c.R; d.S = c.S;
     d.Cin_p = c.Cin_p; d.rows_pad = c.rows_f; d.Kpad = c.Kpad; d.tf = 0;
+    d.Rc = 0; d.r0 = d.rstep = d.s0 = d.sstep = d.Sc = 0;
   }
   RUN(pack_weights_all(dtype, params_, base_, tb, s_));
 }
@@ -173,6 +184,18 @@ void UNet::pack_dgrad_weights() {
     PackDesc& d = tb.d[tb.n++];
     d.w_off = c.w_off; d.dst_off = c.wd; d.Cout = c.Cout; d.Cin = c.Cin; d.R = c.R; d.S = c.S;
     d.Cin_p = c.Cout_p; d.rows_pad = c.rows_d; d.Kpad = c.Kpad_d; d.tf = 1;
+    d.Rc = 0; d.r0 = d.rstep = d.s0 = d.sstep = d.Sc = 0;
+    if (c.parity_dgrad()) {
+      for (int cls = 0; cls < 4; ++cls) {
+        // gather-form tap kr reads dY row (ho - 1 + kr) / 2: even output rows use kr = 1, odd rows kr = 0 and 2
+        PackDesc& e = tb.d[tb.n++];
+        e = d;
+        e.dst_off = c.wd_cls[cls]; e.Kpad = c.Kpad_cls[cls];
+        const int py = cls >> 1, px = cls & 1;
+        e.Rc = py ? 2 : 1; e.r0 = py ? 0 : 1; e.rstep = 2;
+        e.Sc = px ? 2 : 1; e.s0 = px ? 0 : 1; e.sstep = 2;
+      }
+    }
   }
   RUN(pack_weights_all(dtype, params_, base_, tb, s_));
 }
@@ -485,6 +508,21 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
     a.accumulate = acc ? 1 : 0;
     attach_bn_reduce(a, u.in0);
   }
+  const bool doubled = c.stride == 2 && a.Hout == 2 * u.y.H && a.Wout == 2 * u.y.W;
+  if (doubled && (c.parity_dgrad() || (c.R == 1 && c.S == 1 && c.pad == 0 && a.accumulate))) {
+    // stride-2 data gradient by output parity class: stride-1 convolutions over dY, stores interleaved into dX.
+    // A 1x1 stride-2 layer only reaches the (even, even) pixels; when accumulating, the other classes add nothing.
+    a.Hout = u.y.H; a.Wout = u.y.W; a.out_mul = 1; a.pad = 0; a.in_div = 1; a.out_sub = 1;
+    for (int cls = 0; cls < (c.R == 1 ? 1 : 4); ++cls) {
+      a.out_oy = cls >> 1; a.out_ox = cls & 1;
+      if (c.R == 3) {
+        a.R = a.out_oy ? 2 : 1; a.S = a.out_ox ? 2 : 1;
+        a.Kg = c.Kg_cls[cls]; a.Kpad = c.Kpad_cls[cls]; a.w = base_ + c.wd_cls[cls];
+      }
+      RUN(launch_conv(dtype, a, s_));
+    }
+    return;
+  }
   RUN(launch_conv(dtype, a, s_));
 }
 
@@ -540,7 +578,11 @@ void UNet::encoder_bwd_impl() {
       } else {
         void* dz = alloc((size_t)units_[u2].y.elems() * dtype_size(dtype));
         unit_backward(u2, dO, dz, false, true, nullptr);
-        unit_backward(ud, dz, nullptr, false, true, nullptr);  // no ReLU on the downsample branch
+        // conv1 first: its stride-2 data gradient writes every pixel of dX, so the 1x1 stride-2 downsample branch
+        // (no ReLU) then only accumulates into the (even, even) ones
+        unit_backward(u1, grad_peek(units_[u1].out), nullptr, false, true, nullptr);
+        unit_backward(ud, dz, nullptr, false, true, nullptr);
+        continue;
       }
       unit_backward(u1, grad_peek(units_[u1].out), nullptr, false, true, nullptr);
     }

@@ -279,6 +279,9 @@ static void wg_plan(int dtype, const WgradArgs& a, int& bmk, int& bnn, int& spli
 bool wgrad_halo_applicable(const WgradArgs& a);          // wgrad_halo.hip
 size_t wgrad_halo_workspace_bytes(const WgradArgs& a);
 int launch_wgrad_halo(int dtype, const WgradArgs& a, hipStream_t s);
+bool wgrad_stem_applicable(int dtype, const WgradArgs& a);  // stem.hip
+size_t wgrad_stem_workspace_bytes(const WgradArgs& a);
+int launch_wgrad_stem(const WgradArgs& a, hipStream_t s);
 bool wgrad_big_applicable(int dtype, const WgradArgs& a);  // wgrad_hg.hip
 size_t wgrad_big_workspace_bytes(int dtype, const WgradArgs& a);
 int launch_wgrad_big(int dtype, const WgradArgs& a, hipStream_t s);
@@ -294,6 +297,7 @@ void launch_wgrad_reduce(const float* partial, float* dw, int splits, int Cout, 
 }
 
 size_t wgrad_workspace_bytes(int dtype, const WgradArgs& a) {
+  if (wgrad_stem_applicable(dtype, a)) return wgrad_stem_workspace_bytes(a);
   if (wgrad_big_applicable(dtype, a)) return wgrad_big_workspace_bytes(dtype, a);
   if (wgrad_halo_applicable(a)) return wgrad_halo_workspace_bytes(a);
   int bmk, bnn, splits, Kg, Kpad, Cout_pad;
@@ -325,7 +329,8 @@ static int wg_launch(const WgKArgs& ka, int splits, hipStream_t s) {
 int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if ((a.C0 % ch) || (a.C1 % ch) || (a.dy_ld % ch)) return -2;
-  if (wgrad_big_applicable(dtype, a)) return launch_wgrad_big(dtype, a, s);  // MFMA-bound 3x3 s1 layers, >= 128 channels
+  if (wgrad_stem_applicable(dtype, a)) return launch_wgrad_stem(a, s);        // 7x7 stride-2 stem
+  if (wgrad_big_applicable(dtype, a)) return launch_wgrad_big(dtype, a, s);  // MFMA-bound 3x3 s1 layers, >= 64 channels
   if (wgrad_halo_applicable(a)) return launch_wgrad_halo(dtype, a, s);  // HBM-bound small-channel 3x3 layers
   WgKArgs ka;
   ka.a = a;

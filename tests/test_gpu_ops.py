@@ -32,6 +32,7 @@ CONV_CASES = [
     (2, 8, 8, 256, 256, 3, 1, 1),
     (3, 8, 8, 128, 256, 1, 2, 0),
     (2, 32, 32, 8, 64, 7, 2, 3),
+    (3, 64, 96, 8, 64, 7, 2, 3),
     (1, 32, 32, 32, 16, 3, 1, 1),
     (1, 32, 32, 128, 32, 3, 1, 1),
     (2, 4, 4, 512, 512, 3, 1, 1),
