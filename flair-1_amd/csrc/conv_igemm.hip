@@ -332,6 +332,9 @@ static inline int pick_bm(int cout) { return cout >= 64 ? 128 : 256; }
 bool conv_halo_applicable(const ConvArgs& a);           // conv_halo.hip
 int conv_halo_grid_rows(const ConvArgs& a);
 int launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s);
+bool conv_stem_applicable(int dtype, const ConvArgs& a);  // stem.hip
+int conv_stem_grid_rows(const ConvArgs& a);
+int launch_conv_stem(const ConvArgs& a, hipStream_t s);
 bool conv_hg_applicable(int dtype, const ConvArgs& a);  // conv_hg.hip
 int conv_hg_grid_rows(int dtype, const ConvArgs& a);
 int launch_conv_hg(int dtype, const ConvArgs& a, hipStream_t s);
@@ -355,6 +358,7 @@ bool conv_mfma_bound(int dtype, const ConvArgs& a) {
 }
 
 int conv_grid_rows(int dtype, const ConvArgs& a) {
+  if (conv_stem_applicable(dtype, a)) return conv_stem_grid_rows(a);
   if (conv_hg_applicable(dtype, a)) return conv_hg_grid_rows(dtype, a);
   if (conv_halo_applicable(a)) return conv_halo_grid_rows(a);
   return cdiv((long)a.N * a.Hout * a.Wout, pick_bm(a.Cout));
@@ -382,6 +386,7 @@ int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
     return -6;  // sub-sampled stores exist in the gather-form epilogue only
   if (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a)) return -6;
   if (a.bnr_partial && !(conv_tile_epilogue_ok(dtype, a) && conv_hg_applicable(dtype, a))) return -6;  // halo-GEMM epilogue only
+  if (conv_stem_applicable(dtype, a)) return launch_conv_stem(a, s);     // 7x7 stride-2 stem
   if (conv_hg_applicable(dtype, a)) return launch_conv_hg(dtype, a, s);  // MFMA-bound 3x3 s1 layers: halo GEMM
   if (conv_halo_applicable(a)) {  // HBM-bound small-channel 3x3 layers: halo-tile direct kernel
     const int ch = dtype == DT_F32 ? 4 : 8;

@@ -198,4 +198,202 @@ int launch_wgrad_stem(const WgradArgs& a, hipStream_t s) {
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Forward of the same layer (and nothing else): y[p][k] = sum_{(r,s),c} X[2p - 3 + (r,s)][c] * W[k][(r,s),c].
+// The gather-form kernel spends 0.32 ms on it (16-byte gathers, 64-wide column tile).  Here the 49 x 8 = 392-deep
+// reduction runs as 13 MFMA K steps of 4 taps each; a wave keeps its 32 output channels' weights in registers for the
+// whole launch (104 VGPRs), the 21x37 input halo of an 8x16 output tile is staged once in LDS with even and odd
+// columns de-interleaved (so the stride-2 window of a tap is 16 consecutive 16-byte slots: conflict-free ds_read_b128),
+// persistent workgroups prefetch the next halo in registers, BatchNorm partial statistics accumulate in registers over
+// all tiles of a workgroup ([2][64][gridDim.x] partials), and the bf16 tile leaves through LDS as 16-byte stores.
+namespace {
+
+constexpr int FH2 = (HWD + 1) / 2;                              // 19 slots per column parity
+constexpr int FXBYTES = (HH * 2 * FH2 * 16 + 255) / 256 * 256;  // de-interleaved halo image
+constexpr int FCLD = 128 + 16, FCBYTES = TPIX * FCLD;           // output tile [128 px][64 ch] bf16, padded rows
+constexpr int FSMEM = 2 * FXBYTES + 2 * FCBYTES;
+constexpr int KSTEPS = 13;
+
+__global__ __launch_bounds__(NT) void conv_stem_kernel(const ConvArgs a, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nh = wave & 1, ph = wave >> 1;          // output-channel half, tile-row half
+  const int H = a.Hout, W = a.Wout, Hi = a.Hin, Wi = a.Win;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  const bf16_t* __restrict__ x = (const bf16_t*)a.src0;
+  const bf16_t* __restrict__ wp = (const bf16_t*)a.w;
+  bf16_t* __restrict__ out = (bf16_t*)a.out;
+  const int li = lane & 15, lg = lane >> 4;
+
+  // stationary B fragments: column tile j -> output channels (2*nh + j)*16 + li, K step ks -> taps 4*ks + lg
+  u32x4 bw[2][KSTEPS];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+      bw[j][ks] = *reinterpret_cast<const u32x4*>(wp + (long)((2 * nh + j) * 16 + li) * a.Kpad + (4 * ks + lg) * 8);
+  // A fragment addresses: pixel column li of a tile row, tap 4*ks + lg (taps past the 49th have zero weights: any
+  // in-range address will do)
+  int aoff[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    int tap = 4 * ks + lg;
+    tap = tap < TAPS ? tap : TAPS - 1;
+    const int r = tap / 7, s = tap - 7 * r;
+    aoff[ks] = ((r * 2 + (s & 1)) * FH2 + li + (s >> 1)) * 16;
+  }
+  float osc[2], obi[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = (2 * nh + j) * 16 + li;
+    osc[j] = a.oscale ? a.oscale[col] : 1.f;
+    obi[j] = (a.bias ? a.bias[col] : 0.f) + (a.oshift ? a.oshift[col] : 0.f);
+  }
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+
+  u32x4 xr[XITEMS];
+  auto load_tile = [&](int tile) {
+    const bool tok = tile < ntiles;
+    const int tl = tok ? tile : 0;
+    const int n = tl / (tiles_x * tiles_y);
+    const int trem = tl - n * tiles_x * tiles_y;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+#pragma unroll
+    for (int k = 0; k < XITEMS; ++k) {
+      const int it = t + NT * k;
+      const int hy = it / HWD, hx = it - hy * HWD;
+      const int iy = 2 * y0 - 3 + hy, ix = 2 * x0 - 3 + hx;
+      const bool ok = tok && it < HPIX && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+      const unsigned off = ok ? (unsigned)(((n * Hi + iy) * Wi + ix) * 8) : 0u;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
+      xr[k] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_halo = [&](int buf) {
+    unsigned char* xh = smem + buf * FXBYTES;
+#pragma unroll
+    for (int k = 0; k < XITEMS; ++k) {
+      const int it = t + NT * k;
+      const int hy = it / HWD, hx = it - hy * HWD;
+      if (it < HPIX) *reinterpret_cast<u32x4*>(xh + ((hy * 2 + (hx & 1)) * FH2 + (hx >> 1)) * 16) = xr[k];
+    }
+  };
+
+  load_tile(blockIdx.x);
+  store_halo(0);
+  __syncthreads();
+  int it = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+    load_tile(tile + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* xh = smem + (it & 1) * FXBYTES;
+    unsigned char* ct = smem + 2 * FXBYTES + (it & 1) * FCBYTES;
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      u32x4 af[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)   // tile row 4*ph + m starts 2 halo rows (of 2 parities x FH2 slots) further down each
+        af[m] = *reinterpret_cast<const u32x4*>(xh + (4 * ph + m) * (4 * FH2 * 16) + aoff[ks]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[m]), __builtin_bit_cast(bf16x8_t, bw[j][ks]),
+                                                              acc[m][j], 0, 0, 0);
+    }
+    // accumulators -> bf16 tile in LDS (+ running BatchNorm statistics of the ROUNDED values, like the other kernels)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (2 * nh + j) * 16 + li;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = (4 * ph + m) * TW + lg * 4 + e;   // MFMA D: row = 4*(lane >> 4) + e = pixel column, col = lane & 15
+          float f = fmaf(acc[m][j][e], osc[j], obi[j]);
+          if (a.orelu) f = fmaxf(f, 0.f);
+          const bf16_t v = Elem<bf16_t>::from_f(f);
+          const float vf = Elem<bf16_t>::to_f(v);
+          s1[j] += vf;
+          s2[j] = fmaf(vf, vf, s2[j]);
+          *reinterpret_cast<bf16_t*>(ct + row * FCLD + col * 2) = v;
+        }
+    }
+    store_halo((it + 1) & 1);
+    __syncthreads();
+    {
+      const int n = tile / (tiles_x * tiles_y);
+      const int trem = tile - n * tiles_x * tiles_y;
+      const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+#pragma unroll
+      for (int k = 0; k < TPIX * 8 / NT; ++k) {
+        const int idx = t + NT * k;
+        const int px = idx >> 3, ch = idx & 7;
+        const int py = px / TW, pxx = px - py * TW;
+        *reinterpret_cast<uint4*>(out + ((long)(n * H + y0 + py) * W + x0 + pxx) * a.out_ld + ch * 8) =
+            *reinterpret_cast<const uint4*>(ct + px * FCLD + ch * 16);
+      }
+    }
+  }
+  if (a.stats) {
+    // lanes lg = 0..3 and the two tile-row halves hold disjoint pixels of the same columns
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      s1[j] += __shfl_xor(s1[j], 16); s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 16); s2[j] += __shfl_xor(s2[j], 32);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [2 halves][64 cols][2]
+    if (lg == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        red[(ph * 64 + (2 * nh + j) * 16 + li) * 2 + 0] = s1[j];
+        red[(ph * 64 + (2 * nh + j) * 16 + li) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (t < 64) {
+      a.stats[(long)t * gridDim.x + blockIdx.x] = red[t * 2] + red[(64 + t) * 2];
+      a.stats[((long)64 + t) * gridDim.x + blockIdx.x] = red[t * 2 + 1] + red[(64 + t) * 2 + 1];
+    }
+  }
+}
+
+int stem_fwd_blocks(const ConvArgs& a) {
+  const long ntiles = (long)a.N * a.Hout * a.Wout / TPIX;
+  return (int)(ntiles < 512 ? ntiles : 512);
+}
+
+}  // namespace
+
+bool conv_stem_applicable(int dtype, const ConvArgs& a) {
+  return dtype == DT_BF16 && a.R == 7 && a.S == 7 && a.out_mul == 2 && a.in_div == 1 && a.pad == 3 && a.C0 == 8 && a.C1 == 0 &&
+         !a.up0 && a.Cout == 64 && a.out && a.out_ld == 64 && !a.out_nchw && !a.accumulate && !a.ores && !a.in_scale &&
+         a.pool_c0 == 0 && !a.bnr_partial && !a.out_sub && a.Hin == 2 * a.Hout && a.Win == 2 * a.Wout && (a.Hout % TH) == 0 &&
+         (a.Wout % TW) == 0 && a.Kpad >= 8 * 4 * KSTEPS && (long)a.N * a.Hin * a.Win * 8 < (1L << 31);
+}
+
+int conv_stem_grid_rows(const ConvArgs& a) { return stem_fwd_blocks(a); }
+
+int launch_conv_stem(const ConvArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FSMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long M = (long)a.N * a.Hout * a.Wout;
+  {
+    ProfScope ps("conv_stem_bf16", 2.0 * (double)M * 64 * TAPS * 8, ((double)M * 64 + 4.0 * M * 8) * 2.0, s);
+    hipLaunchKernelGGL(conv_stem_kernel, dim3(stem_fwd_blocks(a)), dim3(NT), FSMEM, s, a, (int)(M / TPIX));
+  }
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace flair

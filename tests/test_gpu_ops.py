@@ -281,3 +281,25 @@ def test_conv_halo_kernel(dev, dtype, case):
         dx, dw = ops.conv2d_backward(_nhwc(x0, dtype, dev), wd, _nhwc(dy, dtype, dev))
         assert _rel(dx.float().cpu().permute(0, 3, 1, 2), xin.grad) < TOL[dtype]
         assert _rel(dw.cpu(), w.grad) < TOL[dtype]  # halo-tile weight gradient (all nine taps per workgroup)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32), (3, 64, 96), (1, 128, 128)])
+def test_stem_direct_kernels_bf16(dev, shape):
+    """The 7x7 stride-2 stem in bf16 takes the dedicated direct kernels (stem.hip) when the output is NHWC only:
+    forward + BatchNorm partial statistics and the weight gradient against torch on the same rounded operands."""
+    from flair_amd import ops
+    N, H, W = shape
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(H + W)
+    x = _q(torch.randn(N, 8, H, W, generator=g), dtype)
+    x[:, 5:] = 0  # channels 5..7 are padding in the network
+    w = _q(torch.randn(64, 8, 7, 7, generator=g) / (5 * 49) ** 0.5, dtype).requires_grad_(True)
+    ref = F.conv2d(x, w, stride=2, padding=3)
+    y, _, st = ops.conv2d_forward(_nhwc(x, dtype, dev), w.detach().to(dev), stride=2, pad=3, want_stats=True)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert _rel(got, ref.detach()) < TOL[dtype]
+    assert _rel(st[0].cpu(), got.sum(dim=(0, 2, 3))) < 1e-4 and _rel(st[1].cpu(), (got * got).sum(dim=(0, 2, 3))) < 1e-4
+    dy = _q(torch.randn(ref.shape, generator=g), dtype)
+    ref.backward(dy)
+    _, dw = ops.conv2d_backward(_nhwc(x, dtype, dev), w.detach().to(dev), _nhwc(dy, dtype, dev), stride=2, pad=3, need_dx=False)
+    assert _rel(dw.cpu(), w.grad) < TOL[dtype]
