@@ -109,6 +109,11 @@ struct ConvArgs {
   // optional output sub-sampling (gather-form kernel only): output pixel (ho, wo) is pixel (2*ho + out_oy, 2*wo + out_ox)
   // of a [N][2*Hout][2*Wout][out_ld] tensor — one parity class of a stride-2 data gradient
   int out_sub, out_oy, out_ox;
+  // out_sub with ncls == 4: all four parity classes of a 3x3 stride-2 data gradient in one launch, class = blockIdx.z
+  // = 2*oy + ox, taps (oy ? 2 : 1) x (ox ? 2 : 1), packed weights cls_w[class] with row length cls_kpad[class]
+  int ncls;
+  const void* cls_w[4];
+  int cls_kpad[4];
   // optional fused first pass of the BatchNorm backward of the unit that PRODUCED this conv's input (halo-tile
   // kernels only).  `out` (the pooled part when pool_c0 > 0) is then the complete gradient dz w.r.t. that unit's
   // ReLU output; the epilogue also reads the unit's pre-BN tensor bnr_y (same shape and row stride as `out`) and

@@ -66,6 +66,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const T* __restrict__ src0 = (const T*)a.src0;
   const T* __restrict__ src1 = (const T*)a.src1;
   const T* __restrict__ wp = (const T*)a.w;
+  int cR = a.R, cS = a.S, cKpad = a.Kpad, c_oy = a.out_oy, c_ox = a.out_ox;
+  if (a.ncls) {   // one parity class of a stride-2 data gradient per blockIdx.z
+    const int cls = blockIdx.z;
+    c_oy = cls >> 1; c_ox = cls & 1;
+    cR = c_oy ? 2 : 1; cS = c_ox ? 2 : 1;
+    cKpad = a.cls_kpad[cls];
+    wp = (const T*)a.cls_w[cls];
+  }
 
   int ih0[AROWS], iw0[AROWS], nb[AROWS];
   {
@@ -91,11 +99,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     int kk = cc * CH;
     int tap = kk / Cin;
     kc = kk - tap * Cin;
-    kr = tap / a.S;
-    ks = tap - kr * a.S;
+    kr = tap / cS;
+    ks = tap - kr * cS;
   }
   const int Hs0 = a.up0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.up0 ? (a.Win >> 1) : a.Win;
-  const int nsteps = a.Kpad / BKE;
+  const int nsteps = cKpad / BKE;
 
   // Branch-free gather: every lane always issues its 16-byte load (out-of-image taps read the tensor base
   // and are zeroed by a select when the registers are written to LDS), so all loads of a K step are in
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int Hs = use0 ? Hs0 : a.Hin, Ws = use0 ? Ws0 : a.Win, Cs = use0 ? a.C0 : a.C1;
     const int sh = (use0 && a.up0) ? 1 : 0;
     const int coff = use0 ? kc : kc - a.C0;
-    const bool tap_ok = kr < a.R;
+    const bool tap_ok = kr < cR;
     const int bstep = step < nsteps ? step : nsteps - 1;  // past the end: harmless re-read, never consumed
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
@@ -128,13 +136,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
       const int row = (BN >= 32) ? rb + 32 * j : (rb & (BN - 1));
-      R.b[j] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + row) * a.Kpad + (long)bstep * BKE + cc * CH);
+      R.b[j] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + row) * cKpad + (long)bstep * BKE + cc * CH);
     }
     // advance the K decode by one step
     kc += BKE;
     while (kc >= Cin) {
       kc -= Cin;
-      if (++ks == a.S) { ks = 0; ++kr; }
+      if (++ks == cS) { ks = 0; ++kr; }
     }
   };
   auto write_lds = [&](int stage, const Regs& R) {
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
           const int HWo = a.Hout * a.Wout;
           const int img = (int)(m / HWo), rem = (int)(m - (long)img * HWo);
           const int ho = rem / a.Wout, wo = rem - ho * a.Wout;
-          mo = ((long)img * 2 * a.Hout + 2 * ho + a.out_oy) * (2 * a.Wout) + 2 * wo + a.out_ox;
+          mo = ((long)img * 2 * a.Hout + 2 * ho + c_oy) * (2 * a.Wout) + 2 * wo + c_ox;
         }
         T* dst = out + mo * a.out_ld + n;
         if (a.ores || a.orelu) {
@@ -302,7 +310,7 @@ template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   using Cfg = ConvCfg<T, BM, BN, WAVES_M, WAVES_N>;
   const long M = (long)a.N * a.Hout * a.Wout;
-  dim3 grid(cdiv(M, BM), cdiv(a.Cout, BN));
+  dim3 grid(cdiv(M, BM), cdiv(a.Cout, BN), a.ncls ? a.ncls : 1);
   auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -370,6 +378,9 @@ template <typename T>
 static int launch_t(const ConvArgs& a, hipStream_t s) {
   constexpr int CH = Elem<T>::CH;
   if ((a.C0 % CH) || (a.C1 % CH) || (a.Kpad % (8 * CH))) return -2;
+  if (a.ncls && (a.ncls != 4 || !a.out_sub)) return -2;
+  for (int c = 0; c < a.ncls; ++c)
+    if (!a.cls_w[c] || (a.cls_kpad[c] % (8 * CH))) return -2;
   if (a.out && (a.Cout % CH)) return -3;
   if (a.up0 && ((a.Hin | a.Win) & 1)) return -4;
   if (a.in_div != 1 && a.in_div != 2) return -5;

@@ -513,14 +513,14 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
     // stride-2 data gradient by output parity class: stride-1 convolutions over dY, stores interleaved into dX.
     // A 1x1 stride-2 layer only reaches the (even, even) pixels; when accumulating, the other classes add nothing.
     a.Hout = u.y.H; a.Wout = u.y.W; a.out_mul = 1; a.pad = 0; a.in_div = 1; a.out_sub = 1;
-    for (int cls = 0; cls < (c.R == 1 ? 1 : 4); ++cls) {
-      a.out_oy = cls >> 1; a.out_ox = cls & 1;
-      if (c.R == 3) {
-        a.R = a.out_oy ? 2 : 1; a.S = a.out_ox ? 2 : 1;
-        a.Kg = c.Kg_cls[cls]; a.Kpad = c.Kpad_cls[cls]; a.w = base_ + c.wd_cls[cls];
-      }
-      RUN(launch_conv(dtype, a, s_));
+    if (c.R == 3) {   // the four classes (1, 2, 2 and 4 taps) ride in one launch, class = blockIdx.z
+      a.ncls = 4;
+      a.R = 2; a.S = 2;
+      a.Kg = (c.Kg_cls[0] + c.Kg_cls[1] + c.Kg_cls[2] + c.Kg_cls[3]) / 4;  // mean over the classes (work accounting only)
+      a.Kpad = c.Kpad_cls[3]; a.w = base_ + c.wd_cls[3];
+      for (int cls = 0; cls < 4; ++cls) { a.cls_w[cls] = base_ + c.wd_cls[cls]; a.cls_kpad[cls] = c.Kpad_cls[cls]; }
     }
+    RUN(launch_conv(dtype, a, s_));
     return;
   }
   RUN(launch_conv(dtype, a, s_));
