@@ -298,7 +298,8 @@ int ce_head(const CeArgs& a, hipStream_t s) {
   FLAIR_CHECK_LAUNCH();
   ProfScope* p2 = new ProfScope("ce_main", 0.0, (double)npix * (4.0 * a.C * (1 + (a.dlogits_nchw ? 1 : 0)) + 2 + (a.dlogits_nhwc ? a.dlogits_ld * dtype_size(a.dlogits_dtype) : 0)), s);
   int nb_main = nb;
-  const bool vec4 = (HW % 4) == 0 && (!a.dlogits_nhwc || a.dlogits_ld <= (a.C <= 16 ? 16 : 32));
+  const bool vec4 = (HW % 4) == 0 && (!a.dlogits_nhwc || a.dlogits_ld <= (a.C <= 16 ? 16 : 32)) &&
+                    !(((uintptr_t)a.logits | (uintptr_t)a.dlogits_nchw) & 15) && !((uintptr_t)a.preds_u8 & 3);
   if (vec4) {
     nb_main = ce_blocks(npix / 4);
     auto kern = a.C <= 16 ? ce_main4_kernel<16> : ce_main4_kernel<32>;
@@ -347,11 +348,65 @@ __global__ void softmax_argmax_kernel(const float* __restrict__ logits, int C, l
   }
 }
 
+// four consecutive pixels per thread, 16-byte plane loads (HW % 4 == 0); same arithmetic as above
+template <int CM>
+__global__ __launch_bounds__(256) void softmax_argmax4_kernel(const float* __restrict__ logits, int C, long HW, long npix,
+                                                              unsigned char* __restrict__ preds_u8,
+                                                              long long* __restrict__ preds_i64, float* __restrict__ maxprob) {
+  const long ngroups = npix >> 2;
+  for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (long)gridDim.x * blockDim.x) {
+    const long i = gi << 2;
+    const long n = i / HW, pix = i - n * HW;
+    const float* p = logits + n * C * HW + pix;
+    float4 xv[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c)
+      if (c < C) xv[c] = *reinterpret_cast<const float4*>(p + (long)c * HW);
+    unsigned int pred4 = 0;
+    float pb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float x[CM];
+      float m = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) { x[c] = reinterpret_cast<const float*>(&xv[c])[q]; m = fmaxf(m, x[c]); }
+      float ssum = 0.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) { x[c] = expf(x[c] - m); ssum += x[c]; }
+      int pred = 0;
+      float pbest = -1.f;
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) {
+          const float qv = x[c] / ssum;
+          if (qv > pbest) { pbest = qv; pred = c; }
+        }
+      pred4 |= (unsigned int)pred << (8 * q);
+      pb[q] = pbest;
+    }
+    if (preds_u8) *reinterpret_cast<unsigned int*>(preds_u8 + i) = pred4;
+    if (preds_i64) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) preds_i64[i + q] = (pred4 >> (8 * q)) & 0xff;
+    }
+    if (maxprob) *reinterpret_cast<float4*>(maxprob + i) = float4{pb[0], pb[1], pb[2], pb[3]};
+  }
+}
+
 int softmax_argmax(const float* logits, int B, int C, int H, int W, unsigned char* preds_u8, long long* preds_i64,
                    float* maxprob, hipStream_t s) {
   if (C > MAXC || C < 1) return -2;
   const long HW = (long)H * W, npix = HW * B;
   ProfScope ps("softmax_argmax", 0.0, (double)npix * (4.0 * C + 1), s);
+  const bool aligned = !(((uintptr_t)logits | (uintptr_t)maxprob) & 15) && !((uintptr_t)preds_u8 & 3);
+  if ((HW % 4) == 0 && aligned) {
+    auto kern = C <= 16 ? softmax_argmax4_kernel<16> : softmax_argmax4_kernel<32>;
+    hipLaunchKernelGGL(kern, dim3(ce_blocks(npix / 4)), dim3(256), 0, s, logits, C, HW, npix, preds_u8, preds_i64, maxprob);
+    FLAIR_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(softmax_argmax_kernel, dim3(ce_blocks(npix)), dim3(256), 0, s, logits, C, HW, npix, preds_u8,
                      preds_i64, maxprob);
   FLAIR_CHECK_LAUNCH();
