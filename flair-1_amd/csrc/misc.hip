@@ -205,29 +205,78 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
-// all layers of the network in ONE launch (blockIdx.y = layer): the per-layer table travels as a kernel argument
+// all layers of the network in ONE launch (blockIdx.y = layer): the per-layer table travels as a kernel argument.
+// The fp32 master is OIHW, i.e. for one (k, c) pair the R*S taps are contiguous.  Reads therefore go (k, c)-major with c
+// fastest — a wave covers 64 x R*S contiguous floats — and
+//   forward packs    write dst[k][tap][c] straight from registers (64 consecutive c per tap: 128-byte runs);
+//   data-grad packs  (dst[c][tap'][k], flipped taps) go through a 32(k) x 32(c) x taps LDS tile so that the writes
+//                    run along k (64-byte runs) instead of scattering 2-byte elements over 64 rows.
+// Padding (rows >= real rows, channels >= real channels, row tails) is zero-filled by a second sweep without loads.
 template <typename T>
-__global__ void pack_weights_all_kernel(const float* __restrict__ params, unsigned char* __restrict__ base, const PackTable tb) {
+__global__ __launch_bounds__(256) void pack_weights_all_kernel(const float* __restrict__ params, unsigned char* __restrict__ base,
+                                                              const PackTable tb) {
+  __shared__ float tile[32 * 32 * 9 + 32];
   const PackDesc d = tb.d[blockIdx.y];
   const float* __restrict__ w = params + d.w_off;
   T* __restrict__ dst = reinterpret_cast<T*>(base + d.dst_off);
-  const long total = (long)d.rows_pad * d.Kpad;
+  const int RS = d.R * d.S;
   const int Rc = d.Rc > 0 ? d.Rc : d.R, Sc = d.Rc > 0 ? d.Sc : d.S;
   const int r0 = d.Rc > 0 ? d.r0 : 0, rstep = d.Rc > 0 ? d.rstep : 1, s0 = d.Rc > 0 ? d.s0 : 0, sstep = d.Rc > 0 ? d.sstep : 1;
-  const int RS = Rc * Sc;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(i / d.Kpad), kk = (int)(i - (long)row * d.Kpad);
-    const int tap = kk / d.Cin_p, c = kk - tap * d.Cin_p;
-    float v = 0.f;
-    if (tap < RS) {
-      const int r = r0 + (tap / Sc) * rstep, q = s0 + (tap % Sc) * sstep;
-      if (!d.tf) {
-        if (row < d.Cout && c < d.Cin) v = w[(((long)row * d.Cin + c) * d.R + r) * d.S + q];
-      } else {
-        if (row < d.Cin && c < d.Cout) v = w[(((long)c * d.Cin + row) * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - q)];
+  const int RSc = Rc * Sc;
+  const int t = threadIdx.x;
+  if (!d.tf) {
+    const long nitems = (long)d.Cout * d.Cin;
+    for (long item = (long)blockIdx.x * 256 + t; item < nitems; item += (long)gridDim.x * 256) {
+      const int k = (int)(item / d.Cin), c = (int)(item - (long)k * d.Cin);
+      const float* src = w + item * RS;
+      T* drow = dst + (long)k * d.Kpad + c;
+      for (int tp = 0; tp < RSc; ++tp) {
+        const int r = r0 + (tp / Sc) * rstep, q = s0 + (tp % Sc) * sstep;
+        drow[tp * d.Cin_p] = Elem<T>::from_f(src[r * d.S + q]);
       }
     }
-    dst[i] = Elem<T>::from_f(v);
+  } else if (RS <= 9) {
+    // rows of the pack = forward input channels c (d.Cin of them), columns = (tap', k) with k < d.Cout
+    const int ct = (d.Cin + 31) / 32, kt = (d.Cout + 31) / 32;
+    for (int tl = blockIdx.x; tl < ct * kt; tl += gridDim.x) {
+      const int c0 = (tl % ct) * 32, k0 = (tl / ct) * 32;
+      __syncthreads();
+      for (int e = t; e < 32 * 32; e += 256) {       // load: c fastest
+        const int kk = e >> 5, cc = e & 31;
+        if (k0 + kk < d.Cout && c0 + cc < d.Cin) {
+          const float* src = w + ((long)(k0 + kk) * d.Cin + c0 + cc) * RS;
+          for (int tp = 0; tp < RS; ++tp) tile[(kk * 32 + cc) * RS + tp + (kk >> 3)] = src[tp];
+        }
+      }
+      __syncthreads();
+      for (int e = t; e < 32 * 32 * RSc; e += 256) {   // store: k fastest
+        const int kk = e & 31, rest = e >> 5;
+        const int tp = rest % RSc, cc = rest / RSc;
+        if (k0 + kk < d.Cout && c0 + cc < d.Cin) {
+          const int r = r0 + (tp / Sc) * rstep, q = s0 + (tp % Sc) * sstep;
+          const float v = tile[(kk * 32 + cc) * RS + (d.R - 1 - r) * d.S + (d.S - 1 - q) + (kk >> 3)];
+          dst[(long)(c0 + cc) * d.Kpad + tp * d.Cin_p + k0 + kk] = Elem<T>::from_f(v);
+        }
+      }
+    }
+  } else {   // large filters never need a data-gradient pack in this network; keep a plain path for the op-level API
+    const long total = (long)d.Cin * d.Cout * RSc;
+    for (long i = (long)blockIdx.x * 256 + t; i < total; i += (long)gridDim.x * 256) {
+      const int k = (int)(i % d.Cout);
+      const long rest = i / d.Cout;
+      const int tp = (int)(rest % RSc), c = (int)(rest / RSc);
+      const int r = r0 + (tp / Sc) * rstep, q = s0 + (tp % Sc) * sstep;
+      dst[(long)c * d.Kpad + tp * d.Cin_p + k] =
+          Elem<T>::from_f(w[(((long)k * d.Cin + c) * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - q)]);
+    }
+  }
+  // zero fill of the padding: real region = rows < nrows, per tap columns < ncols
+  const int nrows = d.tf ? d.Cin : d.Cout, ncols = d.tf ? d.Cout : d.Cin;
+  const long total = (long)d.rows_pad * d.Kpad;
+  for (long i = (long)blockIdx.x * 256 + t; i < total; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / d.Kpad), kk = (int)(i - (long)row * d.Kpad);
+    const int tp = kk / d.Cin_p, c = kk - tp * d.Cin_p;
+    if (row >= nrows || tp >= RSc || c >= ncols) dst[i] = Elem<T>::from_f(0.f);
   }
 }
 
