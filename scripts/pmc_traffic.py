@@ -23,21 +23,24 @@ ALIASES = [
 ]
 
 
-def per_kernel(path):
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(path)):
-        a = agg[r["Kernel_Name"]]
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
-    return agg
-
-
 def short(name):
     for pat, alias in ALIASES:
         if re.search(pat, name):
             return alias
     m = re.search(r"(\w+)(<.*>)?\(", name)
     return (m.group(1) + (m.group(2) or "")) if m else name
+
+
+def per_kernel(path):
+    """launch count and counter sum per kernel; template variants that bench.py reports under one name are merged"""
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if "flair" not in r["Kernel_Name"]:
+            continue
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return agg
 
 
 def main():
@@ -47,11 +50,11 @@ def main():
     for k in sorted(set(f) | set(w)):
         nf, vf = f.get(k, (0, 0.0))
         nw, vw = w.get(k, (0, 0.0))
-        if not nf or not nw or "flair" not in k:
+        if not nf or not nw:
             continue
         rd = 2.0 * vf / nf * 1024.0
         wr = vw / nw * 1024.0
-        res[short(k)] = {"launches_sampled": nf, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+        res[k] = {"launches_sampled": nf, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                          "hbm_bytes_per_launch": round(rd + wr)}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 "
                          "--train-only; KiB -> bytes, FETCH_SIZE doubled (gfx950)", "kernels": res}, open(out, "w"), indent=1)
