@@ -60,6 +60,17 @@ template <> __device__ __forceinline__ uint4 f_to_chunk<bf16_t>(const float* f) 
   return r;
 }
 
+// relu(x*sc + sh) on one 16-byte chunk (the bn_act arithmetic: fmaf, fmaxf, round to T)
+template <typename T, typename V>
+__device__ __forceinline__ V chunk_bn_relu(const V& v, const float* sc, const float* sh) {
+  constexpr int CH = Elem<T>::CH;
+  float f[CH];
+  chunk_to_f<T>(__builtin_bit_cast(uint4, v), f);
+#pragma unroll
+  for (int e = 0; e < CH; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
+  return __builtin_bit_cast(V, f_to_chunk<T>(f));
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 
@@ -90,7 +101,10 @@ struct ConvArgs {
   float* out_nchw;   // optional fp32 NCHW [N][Cout][Hout][Wout]
   float* stats;      // optional per-row-block partial sums, channel-major [2][Cout][gridDim.x] (sum, sum of squares)
   int accumulate;    // out += result
-  // optional fused input transform on src0/src1: x' = relu(x*scale[c] + shift[c]) (per concatenated channel)
+  // optional fused input transform (small-channel halo kernels only): the input tensor is a pre-BatchNorm conv
+  // output and the kernel applies x' = relu(x*in_scale[c] + in_shift[c]) per concatenated input channel while it
+  // stages the halo — the activation tensor of the producing unit is never written ("lazy" BN + ReLU).  Pixels
+  // outside the image stay zero.  The rounding is that of bn_act, so results are bit-identical to the materialised path.
   const float* in_scale;
   const float* in_shift;
   // optional fused output epilogue (inference: BatchNorm folded to a per-channel affine, residual, ReLU):
@@ -139,6 +153,8 @@ struct WgradArgs {
   float* dw;                                         // OIHW fp32 [Cout][Cin_real][R][S]
   int Cin_real;                                      // channels of dw (<= C0+C1, rest is padding)
   int accumulate;
+  const float* in_scale;                             // optional lazy BN + ReLU on x (see ConvArgs::in_scale);
+  const float* in_shift;                             // small-channel halo kernel only
 };
 int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);
 size_t wgrad_workspace_bytes(int dtype, const WgradArgs& a);

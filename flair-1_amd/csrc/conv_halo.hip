@@ -52,7 +52,8 @@ struct HaloCfg {
   static constexpr int WITEMS = (BN * 9 * CPP + 255) / 256;
 };
 
-template <typename T, int CK, int BN>
+// LZ: instantiate the lazy BN + ReLU input transform (ConvArgs::in_scale); kept out of the plain variant
+template <typename T, int CK, int BN, bool LZ>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
   using Cfg = HaloCfg<T, CK, BN>;
   constexpr int CH = Cfg::CH, KF = Cfg::KF, CPP = Cfg::CPP, TN = BN / 16, TM = 4;
@@ -99,6 +100,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     const int coff = use0 ? cbase : cbase - a.C0;
     u32x4 hreg[Cfg::HITEMS], wreg[Cfg::WITEMS];
     unsigned hmask[Cfg::HITEMS];
+    // lazy BN + ReLU of the producing unit: a thread always stages the same chunk column (256 % CPP == 0)
+    float lsc[CH], lsh[CH];
+    if (LZ && a.in_scale) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        lsc[e] = a.in_scale[cbase + (t % CPP) * CH + e];
+        lsh[e] = a.in_shift[cbase + (t % CPP) * CH + e];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < Cfg::HITEMS; ++k) {
       const int it = t + 256 * k;
@@ -123,7 +133,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
       const int it = t + 256 * k;
       if (it < HPIX * CPP) {
         const int hp = it / CPP, ch = it - hp * CPP;
-        *reinterpret_cast<u32x4*>(halo + hp * Cfg::PSTRIDE + ch * 16) = hreg[k] & hmask[k];
+        const u32x4 hv = (LZ && a.in_scale) ? chunk_bn_relu<T>(hreg[k], lsc, lsh) : hreg[k];
+        *reinterpret_cast<u32x4*>(halo + hp * Cfg::PSTRIDE + ch * 16) = hv & hmask[k];
       }
     }
 #pragma unroll
@@ -218,10 +229,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
   }
 }
 
-template <typename T, int CK, int BN>
-int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
+template <typename T, int CK, int BN, bool LZ>
+int launch_halo_cfg_l(const ConvArgs& a, hipStream_t s) {
   using Cfg = HaloCfg<T, CK, BN>;
-  auto kern = conv3x3_halo_kernel<T, CK, BN>;
+  auto kern = conv3x3_halo_kernel<T, CK, BN, LZ>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
@@ -242,6 +253,11 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+template <typename T, int CK, int BN>
+int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
+  return a.in_scale ? launch_halo_cfg_l<T, CK, BN, true>(a, s) : launch_halo_cfg_l<T, CK, BN, false>(a, s);
+}
+
 }  // namespace
 
 // The halo kernel serves 3x3 / stride 1 / pad 1 convolutions with <= 32 output channels per workgroup and an
@@ -250,7 +266,6 @@ bool conv_halo_applicable(const ConvArgs& a) {
   const int Cin = a.C0 + a.C1;
   if (a.R != 3 || a.S != 3 || a.out_mul != 1 || a.in_div != 1 || a.pad != 1) return false;
   if (a.Hout != a.Hin || a.Wout != a.Win || (a.Hout % TH) || (a.Wout % TW)) return false;
-  if (a.in_scale) return false;
   if (Cin == 16) return a.C1 == 0 && a.Cout <= 32;
   if ((Cin % 32) || (a.C0 % 32)) return false;
   return Cin <= 128 && a.Cout <= 128 && (a.Cout <= 32 || Cin <= 32);

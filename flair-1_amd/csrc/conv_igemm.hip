@@ -366,6 +366,7 @@ bool conv_mfma_bound(int dtype, const ConvArgs& a) {
 }
 
 int conv_grid_rows(int dtype, const ConvArgs& a) {
+  if (a.in_scale && conv_halo_applicable(a)) return conv_halo_grid_rows(a);
   if (conv_stem_applicable(dtype, a)) return conv_stem_grid_rows(a);
   if (conv_hg_applicable(dtype, a)) return conv_hg_grid_rows(dtype, a);
   if (conv_halo_applicable(a)) return conv_halo_grid_rows(a);
@@ -395,6 +396,12 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
   if (a.out_sub && (a.out_nchw || a.stats || a.pool_c0 > 0 || a.bnr_partial || conv_hg_applicable(dtype, a) || conv_halo_applicable(a)))
     return -6;  // sub-sampled stores exist in the gather-form epilogue only
+  if (a.in_scale) {   // lazy BN + ReLU on the input: the small-channel halo kernel is the only one that applies it
+    if (!conv_halo_applicable(a) || (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a))) return -6;
+    const int ch = dtype == DT_F32 ? 4 : 8;
+    if (a.out && (a.Cout % ch)) return -3;
+    return launch_conv_halo(dtype, a, s);
+  }
   if (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a)) return -6;
   if (a.bnr_partial && !(conv_tile_epilogue_ok(dtype, a) && conv_hg_applicable(dtype, a))) return -6;  // halo-GEMM epilogue only
   if (conv_stem_applicable(dtype, a)) return launch_conv_stem(a, s);     // 7x7 stride-2 stem

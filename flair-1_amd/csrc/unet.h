@@ -13,6 +13,10 @@ namespace flair {
 struct Act {
   void* p = nullptr;
   int N = 0, H = 0, W = 0, C = 0;  // C = stored (padded) channel count
+  // "lazy" activation: p is the producing unit's PRE-BatchNorm tensor and consumers apply relu(x*lz_scale + lz_shift)
+  // while they stage it (ConvArgs::in_scale) — the activation itself is never written
+  const float* lz_scale = nullptr;
+  const float* lz_shift = nullptr;
   long rows() const { return (long)N * H * W; }
   long elems() const { return rows() * C; }
 };
@@ -124,6 +128,7 @@ class UNet {
   int enc_units_end_ = 0, dec_units_begin_ = 0;
   size_t fwd_top_ = 0;      // arena top after forward (backward scratch starts here)
   bool packed_d_ = false;
+  bool lazy_ok_ = false;   // whole-model training forward only: small-channel decoder units hand out lazy activations
   void* dl_nhwc_ = nullptr;
   void* const* stage_events_ = nullptr;
   void stage_done(int stage);

@@ -68,6 +68,7 @@ struct WgHaloArgs {
   float* partial;   // [gridDim.x][Cout_pad][Kg] fp32
   int Cout_pad, Kg;
   int ntiles;
+  const float* in_scale; const float* in_shift;   // lazy BN + ReLU on x (WgradArgs::in_scale)
 };
 
 template <typename T, int CK, int CO>
@@ -87,7 +88,7 @@ struct WgHaloCfg {
   static constexpr int DITEMS = (TH * TW * DPP + 255) / 256;
 };
 
-template <typename T, int CK, int CO>
+template <typename T, int CK, int CO, bool LZ>
 __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) {
   using Cfg = WgHaloCfg<T, CK, CO>;
   constexpr int CH = Cfg::CH, CPP = Cfg::CPP, DPP = Cfg::DPP, COT = Cfg::COT, CIT = Cfg::CIT;
@@ -118,6 +119,14 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
   f32x4_t acc[9];
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) acc[tp] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float lsc[CH], lsh[CH];   // this thread's chunk column of the lazy transform (256 % CPP == 0)
+  if (LZ && a.in_scale) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      lsc[e] = a.in_scale[cbase + (t % CPP) * CH + e];
+      lsh[e] = a.in_shift[cbase + (t % CPP) * CH + e];
+    }
+  }
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int n = tile / (tiles_x * tiles_y);
@@ -154,7 +163,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
       const int it = t + 256 * k;
       if (it < HPIX * CPP) {
         const int hp = it / CPP, ch = it - hp * CPP;
-        *reinterpret_cast<u32x4*>(xh + hp * Cfg::XSTRIDE + ch * 16) = xr[k] & xm[k];
+        const u32x4 xv = (LZ && a.in_scale) ? chunk_bn_relu<T>(xr[k], lsc, lsh) : xr[k];
+        *reinterpret_cast<u32x4*>(xh + hp * Cfg::XSTRIDE + ch * 16) = xv & xm[k];
       }
     }
 #pragma unroll
@@ -217,10 +227,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
   }
 }
 
-template <typename T, int CK, int CO>
-int launch_wg_halo(const WgHaloArgs& a, int nsplit, hipStream_t s) {
+template <typename T, int CK, int CO, bool LZ>
+int launch_wg_halo_l(const WgHaloArgs& a, int nsplit, hipStream_t s) {
   using Cfg = WgHaloCfg<T, CK, CO>;
-  auto kern = wgrad3x3_halo_kernel<T, CK, CO>;
+  auto kern = wgrad3x3_halo_kernel<T, CK, CO, LZ>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
@@ -235,6 +245,11 @@ int launch_wg_halo(const WgHaloArgs& a, int nsplit, hipStream_t s) {
   hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::SMEM, s, a);
   FLAIR_CHECK_LAUNCH();
   return 0;
+}
+
+template <typename T, int CK, int CO>
+int launch_wg_halo(const WgHaloArgs& a, int nsplit, hipStream_t s) {
+  return a.in_scale ? launch_wg_halo_l<T, CK, CO, true>(a, nsplit, s) : launch_wg_halo_l<T, CK, CO, false>(a, nsplit, s);
 }
 
 }  // namespace
@@ -277,6 +292,7 @@ int launch_wgrad_halo(int dtype, const WgradArgs& a, hipStream_t s) {
   h.x0 = a.x0; h.x1 = a.x1; h.C0 = a.C0; h.C1 = a.C1; h.up0 = a.up0; h.N = a.N; h.H = a.Hin; h.W = a.Win;
   h.dy = a.dy; h.dy_ld = a.dy_ld; h.Cout = a.Cout; h.partial = a.partial; h.Cout_pad = Cout_pad; h.Kg = 9 * Cin;
   h.ntiles = (int)((long)a.N * a.Hin * a.Win / (TH * TW));
+  h.in_scale = a.in_scale; h.in_shift = a.in_shift;
   int rc;
   if (dtype == DT_F32) {
     if (CK == 16) rc = CO == 16 ? launch_wg_halo<float, 16, 16>(h, nsplit, s) : launch_wg_halo<float, 16, 32>(h, nsplit, s);
