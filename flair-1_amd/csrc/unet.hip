@@ -274,10 +274,10 @@ int UNet::run_unit(int ci, int bi, const Act& in0, const Act& in1, bool up0, boo
   else
     RUN(bn_eval_coeffs(b.C, params_ + b.g_off, params_ + b.b_off, buffers_ + b.rm_off, buffers_ + b.rv_off, 1e-5f,
                        u.scale, u.shift, s_));
-  // The 16/32-channel decoder units (blocks 3 and 4: 60 % of all BN-apply bytes) feed only small-channel halo kernels,
+  // The 16-channel decoder units (block 4: 45 % of all BN-apply bytes) feed only small-channel halo kernels,
   // which can apply BN + ReLU while staging their input: skip the activation pass and hand out the pre-BN tensor.
   const bool lazy = lazy_ok_ && training_ && materialize && relu && res_unit < 0 && !res.p && c.R == 3 && c.stride == 1 &&
-                    c.Cout_p <= 32 && (Ho % 8) == 0 && (Wo % 32) == 0;
+                    c.Cout_p <= 16 && (Ho % 8) == 0 && (Wo % 32) == 0;
   if (lazy) {
     u.out = u.y;
     u.out.lz_scale = u.scale; u.out.lz_shift = u.shift;
