@@ -149,3 +149,26 @@ def test_gradient_exchange_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert out[0] and out[1]
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under flair-1_amd/ (the shipped package, its build script and kernels) may
+    import, open or mention it as a code path; only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() do."""
+    pkg = os.path.join(ROOT, "flair-1_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        if os.path.basename(dirpath) in ("build", "__pycache__"):
+            continue
+        for f in files:
+            if not f.endswith((".py", ".hip", ".h")):
+                continue
+            txt = open(os.path.join(dirpath, f), errors="ignore").read()
+            if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "oracle/" in txt or "oracle." in txt:
+                offenders.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
+    assert not offenders, offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    # bench.py may use the oracle inside cpu_baseline() only
+    uses = [m.start() for m in re.finditer(r"\boracle\b", bench)]
+    start = bench.index("def cpu_baseline")
+    end = bench.index("\ndef ", start + 1)
+    assert uses and all(start <= u < end for u in uses if "import" in bench[max(0, u - 40):u + 10] or "from" in bench[max(0, u - 10):u])
