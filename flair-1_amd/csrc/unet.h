@@ -128,7 +128,20 @@ class UNet {
   int enc_units_end_ = 0, dec_units_begin_ = 0;
   size_t fwd_top_ = 0;      // arena top after forward (backward scratch starts here)
   bool packed_d_ = false;
-  bool lazy_ok_ = false;   // whole-model training forward only: small-channel decoder units hand out lazy activations
+  bool lazy_ok_ = false;
+  // weight-gradient kernels run on an internal side stream, forked from / joined to the caller's stream with events, so
+  // that their tails overlap the BatchNorm / data-gradient chain of the following units (FLAIR_WGRAD_STREAM=0: off)
+  hipStream_t side_ = nullptr;
+  std::vector<hipEvent_t> fork_ev_;
+  hipEvent_t join_ev_ = nullptr;
+  size_t fork_next_ = 0;
+  bool side_pending_ = false;
+  bool side_init();
+  hipStream_t wgrad_stream();   // forks the side stream behind everything queued on s_ so far
+  void side_join();
+ public:
+  ~UNet();
+ private:   // whole-model training forward only: small-channel decoder units hand out lazy activations
   void* dl_nhwc_ = nullptr;
   void* const* stage_events_ = nullptr;
   void stage_done(int stage);

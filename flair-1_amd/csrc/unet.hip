@@ -122,6 +122,39 @@ void UNet::build_table() {
 
 UNet::UNet(int in_ch, int cls, int dt) : in_channels(in_ch), classes(cls), dtype(dt) { build_table(); }
 
+UNet::~UNet() {
+  for (hipEvent_t e : fork_ev_) (void)hipEventDestroy(e);
+  if (join_ev_) (void)hipEventDestroy(join_ev_);
+  if (side_) (void)hipStreamDestroy(side_);
+}
+
+bool UNet::side_init() {
+  static const int on = [] { const char* e = getenv("FLAIR_WGRAD_STREAM"); return e ? atoi(e) : 1; }();
+  if (!on) return false;
+  if (side_) return true;
+  if (hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) != hipSuccess) { side_ = nullptr; return false; }
+  fork_ev_.resize(64);
+  for (auto& e : fork_ev_)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+  return hipEventCreateWithFlags(&join_ev_, hipEventDisableTiming) == hipSuccess;
+}
+
+hipStream_t UNet::wgrad_stream() {
+  if (dry_ || err_ || !side_init()) return s_;
+  hipEvent_t e = fork_ev_[fork_next_++ % fork_ev_.size()];
+  if (hipEventRecord(e, s_) != hipSuccess || hipStreamWaitEvent(side_, e, 0) != hipSuccess) return s_;
+  side_pending_ = true;
+  return side_;
+}
+
+void UNet::side_join() {
+  if (!side_pending_ || dry_) return;
+  side_pending_ = false;
+  if (hipEventRecord(join_ev_, side_) != hipSuccess || hipStreamWaitEvent(s_, join_ev_, 0) != hipSuccess) {
+    if (!err_) err_ = -13;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ arena
 void* UNet::alloc(size_t bytes) {
   const size_t off = top_;
@@ -479,7 +512,10 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
   w.dw = grads_ + c.w_off; w.Cin_real = c.Cin; w.accumulate = 0;
   w.in_scale = u.in0.lz_scale; w.in_shift = u.in0.lz_shift;
   w.partial = (float*)alloc(wgrad_workspace_bytes(dtype, w));
-  RUN(launch_wgrad(dtype, w, s_));
+  {
+    hipStream_t ws = wgrad_stream();   // dy is complete on s_; nothing later on s_ writes what this kernel reads
+    RUN(launch_wgrad(dtype, w, ws));
+  }
   if (!need_dgrad) return;
   // data gradient: gather-form conv over dy with the flipped / transposed pack
   Act dyact = u.y;
@@ -549,7 +585,10 @@ void UNet::head_bwd_impl(const void* dl) {
   w.dy = dl; w.dy_ld = c.Cout_p; w.Cout = c.Cout; w.dw = grads_ + c.w_off; w.Cin_real = c.Cin;
   w.in_scale = dec_out_.lz_scale; w.in_shift = dec_out_.lz_shift;
   w.partial = (float*)alloc(wgrad_workspace_bytes(dtype, w));
-  RUN(launch_wgrad(dtype, w, s_));
+  {
+    hipStream_t ws = wgrad_stream();
+    RUN(launch_wgrad(dtype, w, ws));
+  }
   // bias gradient = column sums of dl
   const long rows = dec_out_.rows();
   float* partial = alloc_f((long)bn_bwd_blocks(rows) * c.Cout_p);
@@ -612,6 +651,7 @@ void UNet::encoder_bwd_impl() {
 }
 
 void UNet::stage_done(int stage) {
+  side_join();   // the stage's weight gradients (side stream) are part of "done"
   if (stage_events_ && stage_events_[stage] && !dry_ && !err_) {
     hipError_t e = hipEventRecord((hipEvent_t)stage_events_[stage], s_);
     if (e != hipSuccess) err_ = (int)e;
@@ -650,6 +690,7 @@ int UNet::head_backward(const float* params, const float* dlogits_nchw, float* d
   void* t = alloc((size_t)dec_out_.rows() * ld * dtype_size(dtype));
   RUN(nchw_f32_to_nhwc(dtype, dlogits_nchw, t, B_, classes, H_, W_, ld, s_));
   head_bwd_impl(t);
+  side_join();
   RUN(nhwc_to_nchw_f32(dtype, grad_peek(dec_out_), dx_nchw, B_, 16, H_, W_, 16, nullptr, s_));
   return err_;
 }
@@ -664,6 +705,7 @@ int UNet::decoder_backward(const float* params, const float* dout_nchw, float* c
   void* g = grad_of(out, &acc);
   RUN(nchw_f32_to_nhwc(dtype, dout_nchw, g, out.N, 16, out.H, out.W, out.C, s_));
   decoder_bwd_impl();
+  side_join();
   for (int i = 0; i < 5; ++i) {
     const Act& f = dec_in_[i + 1];
     RUN(nhwc_to_nchw_f32(dtype, grad_peek(f), dfeats[i], f.N, f.C, f.H, f.W, f.C, nullptr, s_));
