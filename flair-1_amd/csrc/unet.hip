@@ -651,7 +651,8 @@ void UNet::encoder_bwd_impl() {
 }
 
 void UNet::stage_done(int stage) {
-  side_join();   // the stage's weight gradients (side stream) are part of "done"
+  // the stage's weight gradients (side stream) are part of "done": join when somebody listens for the stage, and at the end
+  if (stage == 0 || (stage_events_ && stage_events_[stage])) side_join();
   if (stage_events_ && stage_events_[stage] && !dry_ && !err_) {
     hipError_t e = hipEventRecord((hipEvent_t)stage_events_[stage], s_);
     if (e != hipSuccess) err_ = (int)e;
