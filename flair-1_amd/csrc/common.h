@@ -128,6 +128,7 @@ struct ConvArgs {
   int ncls;
   const void* cls_w[4];
   int cls_kpad[4];
+  int xcd_remap;   // set by the halo-GEMM launcher: XCD-contiguous workgroup -> work-item map
   // optional fused first pass of the BatchNorm backward of the unit that PRODUCED this conv's input (halo-tile
   // kernels only).  `out` (the pooled part when pool_c0 > 0) is then the complete gradient dz w.r.t. that unit's
   // ReLU output; the epilogue also reads the unit's pre-BN tensor bnr_y (same shape and row stride as `out`) and

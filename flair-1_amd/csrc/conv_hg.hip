@@ -74,11 +74,22 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const 
   const int wm = wave % Cfg::WMN, wn = wave / Cfg::WMN;
   const int H = a.Hout, W = a.Wout;
   const int tiles_x = W / TW, tiles_y = H / TH;
-  const int tile = blockIdx.x;
+  // Work item w = tile * NB + (output-channel block): the NB column blocks of a tile are neighbours in w, and each of the
+  // 8 XCDs (which take consecutive workgroup ids round-robin) gets one contiguous range of w — so the workgroups that
+  // share an input tile, and the tiles that share halo rows, run on the same L2 close in time.
+  const int NB = a.Cout / BN;
+  const int nwork = gridDim.x;
+  int w = blockIdx.x;
+  if (a.xcd_remap) {
+    const int q = nwork >> 3, r = nwork & 7, xcd = w & 7;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+  }
+  const int tile = w / NB;
+  const int ntiles = nwork / NB;
   const int n = tile / (tiles_x * tiles_y);
   const int trem = tile - n * tiles_x * tiles_y;
   const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = (w - tile * NB) * BN;
   const int Cin = a.C0 + a.C1;
   const T* __restrict__ src0 = (const T*)a.src0;
   const T* __restrict__ src1 = (const T*)a.src1;
@@ -254,10 +265,10 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const 
     float x1 = 0.f, x2 = 0.f;
 #pragma unroll
     for (int w = 0; w < Cfg::WMN; ++w) { x1 += st[(w * BN + t) * 2]; x2 += st[(w * BN + t) * 2 + 1]; }
-    a.stats[(long)(n0 + t) * gridDim.x + blockIdx.x] = x1;
-    a.stats[((long)a.Cout + n0 + t) * gridDim.x + blockIdx.x] = x2;
+    a.stats[(long)(n0 + t) * ntiles + tile] = x1;
+    a.stats[((long)a.Cout + n0 + t) * ntiles + tile] = x2;
   }
-  store_tile<T, TW, TPIX, BN, NT, Cfg::CLD, BNR>(a, ct, n, y0, x0, n0, t);
+  store_tile<T, TW, TPIX, BN, NT, Cfg::CLD, BNR>(a, ct, n, y0, x0, n0, t, tile, ntiles);
 }
 
 int g_hg_variant = -1;  // tuning override (FLAIR_HG_VARIANT): 0 = 256 px x 8 waves, 1 = 128 px x 4 waves x 2 WG/CU
@@ -273,14 +284,19 @@ int launch_hg_cfg_b(const ConvArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const long M = (long)a.N * a.Hout * a.Wout;
-  dim3 grid((unsigned)(M / Cfg::TPIX), a.Cout / BN);
+  dim3 grid((unsigned)(M / Cfg::TPIX) * (a.Cout / BN));
+  ConvArgs b = a;
+  {
+    static const int remap = [] { const char* e = getenv("FLAIR_XCD_REMAP"); return e ? atoi(e) : 1; }();
+    b.xcd_remap = remap;
+  }
   {
     const double flops = 2.0 * (double)M * a.Cout * a.Kg;
     const double bytes = ((double)M / (a.up0 ? 4 : 1) * a.C0 + (double)M * a.C1 + (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) +
                          (double)a.Cout * a.Kg * sizeof(T);
     static const char* names[2][2] = {{"conv3x3_hg_f32_n64", "conv3x3_hg_f32_n128"}, {"conv3x3_hg_bf16_n64", "conv3x3_hg_bf16_n128"}};
     ProfScope ps(names[sizeof(T) == 2][BN == 128], flops, bytes, s);
-    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::SMEM, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::SMEM, s, b);
   }
   FLAIR_CHECK_LAUNCH();
   return 0;

@@ -36,8 +36,11 @@ __device__ __forceinline__ void tile_bnr_prefetch(const ConvArgs& a, int n, int 
   }
 }
 
+// tile_id / ntiles index the per-tile partial sums of the fused BN-backward reduction (default: the launch grid's x)
 template <typename T, int TW, int TPIX, int BN, int NT, int CLD, bool BNR = false>
-__device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned char* ct, int n, int y0, int x0, int n0, int t) {
+__device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned char* ct, int n, int y0, int x0, int n0, int t,
+                                           int tile_id = -1, int ntiles = 0) {
+  if (tile_id < 0) { tile_id = blockIdx.x; ntiles = gridDim.x; }
   constexpr int CH = Elem<T>::CH;
   constexpr int CPR = BN / CH;
   static_assert(NT % CPR == 0 && CPR <= 64, "a thread must keep one chunk column across its items");
@@ -86,8 +89,8 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
       float x1 = 0.f, x2 = 0.f;
 #pragma unroll
       for (int w = 0; w < NT / 64; ++w) { x1 += red[(w * BN + t) * 2]; x2 += red[(w * BN + t) * 2 + 1]; }
-      a.bnr_partial[(long)(n0 + t) * gridDim.x + blockIdx.x] = x1;
-      a.bnr_partial[((long)a.bnr_C + n0 + t) * gridDim.x + blockIdx.x] = x2;
+      a.bnr_partial[(long)(n0 + t) * ntiles + tile_id] = x1;
+      a.bnr_partial[((long)a.bnr_C + n0 + t) * ntiles + tile_id] = x2;
     }
   };
   if (a.pool_c0 > 0 && n0 < a.pool_c0) {
