@@ -116,6 +116,21 @@ int flair_ce_head(const float* logits, const void* labels, int label_kind, const
   a.targets_i32 = targets_i32; a.confmat = (long long*)confmat; a.workspace = (float*)workspace;
   return ce_head(a, (hipStream_t)stream);
 }
+const void* flair_unet_logits_nhwc(const flair_unet_t* h) { return h ? h->net.logits_nhwc() : nullptr; }
+
+int flair_ce_head_nhwc(const void* logits_nhwc, int dtype, int ld, const void* labels, int label_kind, const float* weight,
+                       int B, int C, int H, int W, float* loss, void* dl_nhwc, uint8_t* preds_u8, int32_t* targets_i32,
+                       int64_t* confmat, void* workspace, void* stream) {
+  if (!logits_nhwc || !labels || !loss || !workspace || label_kind < 0 || label_kind > 3) return -1;
+  if (dtype != DT_F32 && dtype != DT_BF16) return -2;
+  CeArgs a;
+  a.logits = nullptr; a.logits_nhwc = logits_nhwc; a.logits_dtype = dtype; a.logits_ld = ld;
+  a.labels = labels; a.label_kind = label_kind; a.weight = weight;
+  a.B = B; a.C = C; a.H = H; a.W = W; a.loss = loss; a.dlogits_nchw = nullptr; a.dlogits_nhwc = dl_nhwc;
+  a.dlogits_dtype = dtype; a.dlogits_ld = ld; a.preds_u8 = preds_u8; a.preds_i64 = nullptr;
+  a.targets_i32 = targets_i32; a.confmat = (long long*)confmat; a.workspace = (float*)workspace;
+  return ce_head(a, (hipStream_t)stream);
+}
 int flair_softmax_argmax(const float* logits, int B, int C, int H, int W, uint8_t* preds_u8, int64_t* preds_i64,
                          float* maxprob, void* stream) {
   if (!logits) return -1;

@@ -280,6 +280,73 @@ __global__ __launch_bounds__(256) void ce_main4_kernel(const float* __restrict__
   }
 }
 
+// The same head over logits kept in the network's own layout (NHWC T, row stride ld >= C, what the head convolution
+// writes when nobody asks for fp32 NCHW logits): one pixel per thread, the whole row in ld*sizeof(T) contiguous bytes.
+// In bf16 mode the NCHW fp32 logits are the same bf16 values widened, so both layouts give bit-identical results.
+template <typename T, int LD>
+__global__ __launch_bounds__(256) void ce_main_nhwc_kernel(const T* __restrict__ logits, const unsigned char* __restrict__ lab8,
+                                                           const float* __restrict__ weight, const float* __restrict__ den,
+                                                           int C, long npix, float* __restrict__ loss_partial,
+                                                           void* __restrict__ dl_nhwc, int dl_ld,
+                                                           unsigned char* __restrict__ preds_u8, long long* __restrict__ confmat) {
+  constexpr int CH = Elem<T>::CH;
+  __shared__ float sh[4];
+  __shared__ unsigned int hist[MAXC * MAXC];
+  if (confmat) {
+    for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0;
+    __syncthreads();
+  }
+  const float inv_den = 1.f / den[0];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    float x[MAXC];
+#pragma unroll
+    for (int c0 = 0; c0 < LD; c0 += CH) chunk_to_f<T>(*reinterpret_cast<const uint4*>(logits + i * LD + c0), x + c0);
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < LD; ++c)
+      if (c < C) m = fmaxf(m, x[c]);
+    const int y = lab8[i];
+    const bool ok = y < C;
+    float xy = 0.f, ssum = 0.f;
+#pragma unroll
+    for (int c = 0; c < LD; ++c)
+      if (c < C) {
+        if (c == y) xy = x[c];
+        x[c] = expf(x[c] - m);
+        ssum += x[c];
+      }
+    int pred = 0;
+    float pbest = -1.f;
+#pragma unroll
+    for (int c = 0; c < LD; ++c)
+      if (c < C) {
+        x[c] = x[c] / ssum;
+        if (x[c] > pbest) { pbest = x[c]; pred = c; }
+      }
+    const float w = ok ? (weight ? weight[y] : 1.f) : 0.f;
+    if (ok) acc += w * (logf(ssum) - (xy - m));
+    if (preds_u8) preds_u8[i] = (unsigned char)pred;
+    if (confmat && ok) atomicAdd(&hist[y * C + pred], 1u);
+    if (dl_nhwc) {
+      const float sc = w * inv_den;
+      float gq[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) gq[c] = (c < LD && c < C) ? (x[c < LD ? c : 0] - ((ok && c == y) ? 1.f : 0.f)) * sc : 0.f;
+      store_row<T>((T*)dl_nhwc + i * dl_ld, gq, C, dl_ld);
+    }
+  }
+  const float r = block_sum(acc, sh);
+  if (threadIdx.x == 0) loss_partial[blockIdx.x] = r;
+  if (confmat) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += 256) {
+      const unsigned int v = hist[i];
+      if (v) atomicAdd(reinterpret_cast<unsigned long long*>(confmat + i), (unsigned long long)v);
+    }
+  }
+}
+
 int ce_head(const CeArgs& a, hipStream_t s) {
   if (a.C > MAXC || a.C < 1) return -2;
   if (a.dlogits_nhwc && (a.dlogits_ld < a.C || a.dlogits_ld > MAXC || a.dlogits_ld % (a.dlogits_dtype == DT_F32 ? 4 : 8))) return -3;
@@ -296,6 +363,25 @@ int ce_head(const CeArgs& a, hipStream_t s) {
   delete p1;
   hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, s, den_partial, nb, den, (const float*)nullptr);
   FLAIR_CHECK_LAUNCH();
+  if (a.logits_nhwc) {
+    const int ld = a.logits_ld;
+    if ((ld != 16 && ld != 32) || ld < a.C || a.dlogits_nchw || a.preds_i64 || (a.dlogits_nhwc && (a.dlogits_ld != ld || a.dlogits_dtype != a.logits_dtype)))
+      return -3;
+    ProfScope ps("ce_main", 0.0, (double)npix * (2.0 * ld * dtype_size(a.logits_dtype) + 2), s);
+    if (a.logits_dtype == DT_F32) {
+      auto kern = ld == 16 ? ce_main_nhwc_kernel<float, 16> : ce_main_nhwc_kernel<float, 32>;
+      hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, (const float*)a.logits_nhwc, lab8, a.weight, den, a.C, npix, loss_partial,
+                         a.dlogits_nhwc, a.dlogits_ld, a.preds_u8, a.confmat);
+    } else {
+      auto kern = ld == 16 ? ce_main_nhwc_kernel<bf16_t, 16> : ce_main_nhwc_kernel<bf16_t, 32>;
+      hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, (const bf16_t*)a.logits_nhwc, lab8, a.weight, den, a.C, npix, loss_partial,
+                         a.dlogits_nhwc, a.dlogits_ld, a.preds_u8, a.confmat);
+    }
+    FLAIR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, s, loss_partial, nb, a.loss, den);
+    FLAIR_CHECK_LAUNCH();
+    return 0;
+  }
   ProfScope* p2 = new ProfScope("ce_main", 0.0, (double)npix * (4.0 * a.C * (1 + (a.dlogits_nchw ? 1 : 0)) + 2 + (a.dlogits_nhwc ? a.dlogits_ld * dtype_size(a.dlogits_dtype) : 0)), s);
   int nb_main = nb;
   const bool vec4 = (HW % 4) == 0 && (!a.dlogits_nhwc || a.dlogits_ld <= (a.C <= 16 ? 16 : 32)) &&

@@ -399,7 +399,9 @@ int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
   if (a.in_scale) {   // lazy BN + ReLU on the input: the small-channel halo kernel is the only one that applies it
     if (!conv_halo_applicable(a) || (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a))) return -6;
     const int ch = dtype == DT_F32 ? 4 : 8;
-    if (a.out && (a.Cout % ch)) return -3;
+    // the tile epilogue stores whole 16-byte chunks: a ragged channel count needs the row padded to the next chunk
+    // (the padded columns receive the zero-weight rows' results)
+    if (a.out && (a.Cout % ch) && a.out_ld < (int)round_up(a.Cout, ch)) return -3;
     return launch_conv_halo(dtype, a, s);
   }
   if (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a)) return -6;
@@ -408,7 +410,9 @@ int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
   if (conv_hg_applicable(dtype, a)) return launch_conv_hg(dtype, a, s);  // MFMA-bound 3x3 s1 layers: halo GEMM
   if (conv_halo_applicable(a)) {  // HBM-bound small-channel 3x3 layers: halo-tile direct kernel
     const int ch = dtype == DT_F32 ? 4 : 8;
-    if (a.out && (a.Cout % ch)) return -3;
+    // the tile epilogue stores whole 16-byte chunks: a ragged channel count needs the row padded to the next chunk
+    // (the padded columns receive the zero-weight rows' results)
+    if (a.out && (a.Cout % ch) && a.out_ld < (int)round_up(a.Cout, ch)) return -3;
     return launch_conv_halo(dtype, a, s);
   }
   return dtype == DT_F32 ? launch_t<float>(a, s) : launch_t<bf16_t>(a, s);

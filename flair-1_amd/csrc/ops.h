@@ -55,7 +55,9 @@ int fill_f32(float* p, long n, float v, hipStream_t s);
 
 // ---- ce_head.hip
 struct CeArgs {
-  const float* logits;        // NCHW fp32 [B][C][H][W]
+  const float* logits;        // NCHW fp32 [B][C][H][W]   (or null with logits_nhwc set)
+  const void* logits_nhwc = nullptr;   // NHWC T [B*H*W][logits_ld]: the head convolution's own output layout
+  int logits_dtype = 0, logits_ld = 0;
   const void* labels;         // label map, dtype per label_kind
   int label_kind;             // 0: uint8 [B][H][W]; 1: int32; 2: int64; 3: fp32 one-hot NCHW [B][C][H][W]
   const float* weight;        // optional class weights [C]

@@ -104,6 +104,7 @@ class UNet {
                        size_t ws_bytes, hipStream_t s);
 
   void* last_dlogits_nhwc() const { return dl_nhwc_; }
+  const void* logits_nhwc() const { return logits_nhwc_; }
   int head_ld() const { return 16 > classes ? 16 : (int)round_up(classes, 8); }
 
  private:
@@ -143,6 +144,7 @@ class UNet {
   ~UNet();
  private:   // whole-model training forward only: small-channel decoder units hand out lazy activations
   void* dl_nhwc_ = nullptr;
+  void* logits_nhwc_ = nullptr;   // head output kept in NHWC T when forward() was called without an NCHW logits buffer
   void* const* stage_events_ = nullptr;
   void stage_done(int stage);
 

@@ -177,6 +177,7 @@ void UNet::begin(void* ws, size_t ws_bytes, hipStream_t s, bool dry) {
   gbufs_.clear();
   packed_d_ = false;
   dl_nhwc_ = nullptr;
+  logits_nhwc_ = nullptr;
   // weight arena
   for (auto& c : convs) {
     c.wf = top_; alloc((size_t)c.rows_f * c.Kpad * dtype_size(dtype));
@@ -377,8 +378,17 @@ void UNet::head_fwd_impl(float* logits_nchw) {
   y.N = dec_out_.N; y.H = dec_out_.H; y.W = dec_out_.W; y.C = c.Cout_p; y.p = nullptr;
   ConvArgs a;
   fill_conv_args(a, c, dec_out_, none, false, y, base_ + c.wf);
-  a.out = nullptr;
-  a.out_nchw = logits_nchw;
+  if (logits_nchw || dry_) {
+    a.out = nullptr;
+    a.out_nchw = logits_nchw;
+    logits_nhwc_ = nullptr;
+  }
+  if (!logits_nchw) {
+    // nobody asked for fp32 NCHW logits (the fused trainer): keep them in the network's layout, [B*H*W][Cout_p] T, for
+    // flair_ce_head_nhwc — 40 % fewer bytes than the NCHW fp32 tensor and contiguous rows on both sides
+    logits_nhwc_ = alloc((size_t)dec_out_.rows() * c.Cout_p * dtype_size(dtype));
+    if (!dry_) { a.out = logits_nhwc_; a.out_ld = c.Cout_p; a.out_nchw = nullptr; }
+  }
   a.bias = params_ + c.b_off;
   RUN(launch_conv(dtype, a, s_));
 }

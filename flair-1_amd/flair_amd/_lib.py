@@ -41,6 +41,8 @@ PROTOTYPES = {
     "flair_unet_encoder_backward": (i32, [vp, vp, C.POINTER(vp), vp, vp, sz, vp]),
     "flair_ce_workspace_bytes": (sz, [i32, i32, i32]),
     "flair_ce_head": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "flair_unet_logits_nhwc": (vp, [vp]),
+    "flair_ce_head_nhwc": (i32, [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "flair_softmax_argmax": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "flair_confmat_update": (i32, [vp, i32, vp, i32, i64, i32, vp, vp]),
     "flair_jaccard": (i32, [vp, i32, vp, vp, vp, vp]),

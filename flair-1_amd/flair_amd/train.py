@@ -111,12 +111,13 @@ class SegTrainer:
         m = self.model
         B, _, H, W = img.shape
         ld = self._buffers(B, H, W)
-        logits = m._c_forward(img, training=True)
+        m._c_forward(img, training=True, want_logits=False)   # logits stay in the workspace, NHWC of the compute dtype
         kind = 3 if labels.dtype == torch.float32 else ops._LABEL_KIND[labels.dtype]
         l = L.lib()
-        L.check(l.flair_ce_head(L.ptr(logits), L.ptr(labels), kind, L.ptr(self.class_weight), B, m.classes, H, W,
-                                L.ptr(self.loss), None, L.ptr(self._dl), m._dt, ld, L.ptr(self._preds), None, None,
-                                L.ptr(self.confmat), L.ptr(self._ce_ws), L.stream()), "ce_head")
+        L.check(l.flair_ce_head_nhwc(l.flair_unet_logits_nhwc(m._h), m._dt, ld, L.ptr(labels.contiguous()), kind,
+                                     L.ptr(self.class_weight), B, m.classes, H, W, L.ptr(self.loss), L.ptr(self._dl),
+                                     L.ptr(self._preds), None, L.ptr(self.confmat), L.ptr(self._ce_ws), L.stream()),
+                "ce_head_nhwc")
         if self.exchange and self.overlap:
             m._c_backward(dlogits_nhwc=self._dl, grads=self.grads, stage_events=self.events)
             works = []

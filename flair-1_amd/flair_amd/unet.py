@@ -393,11 +393,13 @@ class Unet(nn.Module):
         """num_batches_tracked += 1 for BatchNorm layers [lo, hi) (one op on the flat int64 buffer)."""
         self._flat_n[lo:hi] += 1
 
-    def _c_forward(self, x, training):
+    def _c_forward(self, x, training, want_logits=True):
+        """want_logits=False (fused trainer): the head's output stays in the workspace as NHWC rows of the compute dtype
+        (flair_unet_logits_nhwc) and no fp32 NCHW tensor is produced; returns None."""
         x = self._prep(x)
         B, _, H, W = x.shape
         ws = self._workspace(B, H, W, training)
-        logits = torch.empty(B, self.classes, H, W, dtype=torch.float32, device=x.device)
+        logits = torch.empty(B, self.classes, H, W, dtype=torch.float32, device=x.device) if want_logits else None
         L.check(L.lib().flair_unet_forward(self._h, L.ptr(self._flat_p), L.ptr(self._flat_b), L.ptr(x), L.ptr(logits), B, H, W,
                                            int(training), L.ptr(ws), ws.numel(), L.stream()), "flair_unet_forward")
         if training:

@@ -89,6 +89,16 @@ int flair_ce_head(const float* logits_nchw, const void* labels, int label_kind, 
                   int H, int W, float* loss, float* dlogits_nchw, void* dlogits_nhwc, int dlogits_dtype, int dlogits_ld,
                   uint8_t* preds_u8, int64_t* preds_i64, int32_t* targets_i32, int64_t* confmat, void* workspace,
                   void* stream);
+/* The same head over logits left in the network's own layout: flair_unet_forward called with logits_nchw == NULL
+ * (training) keeps the segmentation head's output as NHWC rows [B*H*W][flair_unet_head_ld()] of the model's compute
+ * dtype inside the workspace; flair_unet_logits_nhwc returns that buffer (valid until the next forward on the arena).
+ * Same arithmetic and outputs as flair_ce_head (in bf16 mode the fp32 NCHW logits are these values widened); dl_nhwc has
+ * the layout flair_unet_backward takes.  Replaces task_module.py:71-79 + tasks_utils.py:88-93 for a loop that never
+ * looks at the logits themselves (flair_amd.SegTrainer). */
+const void* flair_unet_logits_nhwc(const flair_unet_t* h);
+int flair_ce_head_nhwc(const void* logits_nhwc, int dtype, int ld, const void* labels, int label_kind,
+                       const float* class_weight, int B, int C, int H, int W, float* loss, void* dlogits_nhwc,
+                       uint8_t* preds_u8, int32_t* targets_i32, int64_t* confmat, void* workspace, void* stream);
 /* predict_step: argmax(softmax(logits)) — task_module.py:211-212; with maxprob also
  * zone_detect inference + convert('argmax') — src/zone_detect/compare.py:35, dataset.py:23-30. */
 int flair_softmax_argmax(const float* logits_nchw, int B, int C, int H, int W, uint8_t* preds_u8, int64_t* preds_i64,
