@@ -131,6 +131,12 @@ int flair_ce_head_nhwc(const void* logits_nhwc, int dtype, int ld, const void* l
   a.targets_i32 = targets_i32; a.confmat = (long long*)confmat; a.workspace = (float*)workspace;
   return ce_head(a, (hipStream_t)stream);
 }
+int flair_softmax_argmax_nhwc(const void* logits_nhwc, int dtype, int ld, int B, int C, int H, int W, uint8_t* preds_u8,
+                              int64_t* preds_i64, float* maxprob, void* stream) {
+  if (!logits_nhwc) return -1;
+  if (dtype != DT_F32 && dtype != DT_BF16) return -2;
+  return softmax_argmax_nhwc(logits_nhwc, dtype, ld, (long)B * H * W, C, preds_u8, (long long*)preds_i64, maxprob, (hipStream_t)stream);
+}
 int flair_softmax_argmax(const float* logits, int B, int C, int H, int W, uint8_t* preds_u8, int64_t* preds_i64,
                          float* maxprob, void* stream) {
   if (!logits) return -1;

@@ -481,6 +481,54 @@ __global__ __launch_bounds__(256) void softmax_argmax4_kernel(const float* __res
   }
 }
 
+// argmax(softmax) over logits kept NHWC in the network's dtype (see ce_main_nhwc_kernel)
+template <typename T, int LD>
+__global__ __launch_bounds__(256) void softmax_argmax_nhwc_kernel(const T* __restrict__ logits, int C, long npix,
+                                                                  unsigned char* __restrict__ preds_u8,
+                                                                  long long* __restrict__ preds_i64, float* __restrict__ maxprob) {
+  constexpr int CH = Elem<T>::CH;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    float x[MAXC];
+#pragma unroll
+    for (int c0 = 0; c0 < LD; c0 += CH) chunk_to_f<T>(*reinterpret_cast<const uint4*>(logits + i * LD + c0), x + c0);
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < LD; ++c)
+      if (c < C) m = fmaxf(m, x[c]);
+    float ssum = 0.f;
+#pragma unroll
+    for (int c = 0; c < LD; ++c)
+      if (c < C) { x[c] = expf(x[c] - m); ssum += x[c]; }
+    int pred = 0;
+    float pbest = -1.f;
+#pragma unroll
+    for (int c = 0; c < LD; ++c)
+      if (c < C) {
+        const float q = x[c] / ssum;
+        if (q > pbest) { pbest = q; pred = c; }
+      }
+    if (preds_u8) preds_u8[i] = (unsigned char)pred;
+    if (preds_i64) preds_i64[i] = pred;
+    if (maxprob) maxprob[i] = pbest;
+  }
+}
+
+int softmax_argmax_nhwc(const void* logits, int dtype, int ld, long npix, int C, unsigned char* preds_u8, long long* preds_i64,
+                        float* maxprob, hipStream_t s) {
+  if (C > MAXC || C < 1 || (ld != 16 && ld != 32) || ld < C) return -2;
+  ProfScope ps("softmax_argmax", 0.0, (double)npix * (ld * dtype_size(dtype) + 1), s);
+  const dim3 grid(ce_blocks(npix));
+  if (dtype == DT_F32) {
+    auto kern = ld == 16 ? softmax_argmax_nhwc_kernel<float, 16> : softmax_argmax_nhwc_kernel<float, 32>;
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, (const float*)logits, C, npix, preds_u8, preds_i64, maxprob);
+  } else {
+    auto kern = ld == 16 ? softmax_argmax_nhwc_kernel<bf16_t, 16> : softmax_argmax_nhwc_kernel<bf16_t, 32>;
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, (const bf16_t*)logits, C, npix, preds_u8, preds_i64, maxprob);
+  }
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
 int softmax_argmax(const float* logits, int B, int C, int H, int W, unsigned char* preds_u8, long long* preds_i64,
                    float* maxprob, hipStream_t s) {
   if (C > MAXC || C < 1) return -2;

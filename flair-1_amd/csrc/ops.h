@@ -76,6 +76,8 @@ size_t ce_workspace_floats(int B, int H, int W);
 int ce_head(const CeArgs& a, hipStream_t s);
 int softmax_argmax(const float* logits, int B, int C, int H, int W, unsigned char* preds_u8, long long* preds_i64,
                    float* maxprob, hipStream_t s);
+int softmax_argmax_nhwc(const void* logits, int dtype, int ld, long npix, int C, unsigned char* preds_u8, long long* preds_i64,
+                        float* maxprob, hipStream_t s);
 int confmat_update(const void* target, int target_kind, const void* pred, int pred_kind, long n, int C,
                    long long* confmat, hipStream_t s);
 int jaccard_from_confmat(const long long* confmat, int C, float* per_class, float* weighted, float* macro, hipStream_t s);

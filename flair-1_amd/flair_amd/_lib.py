@@ -43,6 +43,7 @@ PROTOTYPES = {
     "flair_ce_head": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     "flair_unet_logits_nhwc": (vp, [vp]),
     "flair_ce_head_nhwc": (i32, [vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "flair_softmax_argmax_nhwc": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "flair_softmax_argmax": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "flair_confmat_update": (i32, [vp, i32, vp, i32, i64, i32, vp, vp]),
     "flair_jaccard": (i32, [vp, i32, vp, vp, vp, vp]),

@@ -138,5 +138,11 @@ class SegTrainer:
     @torch.no_grad()
     def predict(self, img):
         """predict_step of the reference (task_module.py:206-213): (B,H,W) uint8 argmax(softmax(logits))."""
-        logits = self.model._c_forward(img, training=False)
-        return ops.softmax_argmax(logits, want="u8")
+        m = self.model
+        B, _, H, W = img.shape
+        m._c_forward(img, training=False, want_logits=False)   # logits stay NHWC in the workspace
+        preds = torch.empty(B, H, W, dtype=torch.uint8, device=img.device)
+        l = L.lib()
+        L.check(l.flair_softmax_argmax_nhwc(l.flair_unet_logits_nhwc(m._h), m._dt, l.flair_unet_head_ld(m._h), B, m.classes, H, W,
+                                            L.ptr(preds), None, None, L.stream()), "softmax_argmax_nhwc")
+        return preds

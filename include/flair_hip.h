@@ -99,6 +99,9 @@ const void* flair_unet_logits_nhwc(const flair_unet_t* h);
 int flair_ce_head_nhwc(const void* logits_nhwc, int dtype, int ld, const void* labels, int label_kind,
                        const float* class_weight, int B, int C, int H, int W, float* loss, void* dlogits_nhwc,
                        uint8_t* preds_u8, int32_t* targets_i32, int64_t* confmat, void* workspace, void* stream);
+/* predict_step over NHWC logits left in the workspace (flair_unet_forward with logits_nchw == NULL, flair_unet_logits_nhwc). */
+int flair_softmax_argmax_nhwc(const void* logits_nhwc, int dtype, int ld, int B, int C, int H, int W, uint8_t* preds_u8,
+                              int64_t* preds_i64, float* maxprob, void* stream);
 /* predict_step: argmax(softmax(logits)) — task_module.py:211-212; with maxprob also
  * zone_detect inference + convert('argmax') — src/zone_detect/compare.py:35, dataset.py:23-30. */
 int flair_softmax_argmax(const float* logits_nchw, int B, int C, int H, int W, uint8_t* preds_u8, int64_t* preds_i64,

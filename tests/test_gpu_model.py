@@ -346,3 +346,28 @@ def test_bf16_tracks_fp32_like_torch_autocast_on_ragged_shapes(dev, shape):
     assert hip_cos >= amp_cos - 0.05, (hip_cos, amp_cos)
     # and the fp32 HIP gradients point where torch-CPU fp32's do
     assert med([cos(g32[k], c32[k]) for k in g32]) > 0.999
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_nhwc_logits_head_paths_equal_the_nchw_ones(dev, dtype):
+    """The fused trainer never materialises fp32 NCHW logits (flair_ce_head_nhwc / flair_softmax_argmax_nhwc over the
+    head's NHWC output): loss, predictions, confusion matrix and masks must equal the NCHW entry points bit for bit."""
+    import flair_amd
+    from flair_amd import ops
+    _, hip = _pair(5, 13, 9, dev, dtype)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 5, 64, 96, generator=g).to(dev)
+    lab = torch.randint(0, 15, (2, 64, 96), generator=g).to(torch.uint8).to(dev)   # labels >= 13 carry no weight
+    w = torch.linspace(0.5, 1.5, 13)
+    w[4] = 0.0
+    tr = flair_amd.SegTrainer(hip.train(), lr=0.0, class_weight=w)
+    loss_t = tr.train_step(x, lab).item()
+    preds_t, cm_t = tr._preds.clone(), tr.confmat.clone()
+    logits = hip._c_forward(x, training=True)            # same weights (lr = 0), same batch statistics
+    cm = torch.zeros(13, 13, dtype=torch.int64, device=dev)
+    loss, _, preds, _ = ops.ce_head(logits, lab, w.to(dev), want_dlogits=False, want_preds="u8", confmat=cm)
+    assert abs(loss_t - loss.item()) <= 2e-6 * abs(loss_t)   # same terms, different partial-sum grouping
+    assert torch.equal(preds_t, preds) and torch.equal(cm_t, cm)
+    hip.eval()
+    with torch.no_grad():
+        assert torch.equal(tr.predict(x), ops.softmax_argmax(hip(x).float().contiguous(), want="u8"))
