@@ -19,12 +19,14 @@ const char* flair_strerror(int code) {
   switch (code) {
     case -1: return "null or invalid handle";
     case -2: return "channel count / pointer alignment not supported by the kernel";
-    case -3: return "output channel count not a multiple of the 16-byte chunk";
+    case -3: return "output rows too short for whole 16-byte chunks (channel count / row stride)";
     case -4: return "fused upsample needs even extents";
     case -5: return "unsupported stride";
+    case -6: return "requested fused epilogue / input transform is not available in the kernel this shape dispatches to";
     case -10: return "Wrong input shape: height and width must be divisible by 32";
     case -11: return "call order: backward / stage call without the matching forward on this workspace";
     case -12: return "gradient buffer already initialised";
+    case -13: return "internal side stream: event record / wait failed";
     case -100: return "workspace too small";
     default: return "invalid argument";
   }
