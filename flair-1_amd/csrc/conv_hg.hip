@@ -38,13 +38,16 @@ template <> struct GMma<float> {
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 // TW x TH output pixels per workgroup (128 or 256), BN output channels (64 or 128), HB halo buffers (1 or 2)
-template <typename T, int TW, int TH, int BN, int HB>
+// TMv: 16-pixel row segments per wave.  4 = a 64 x 64 accumulator tile per wave (what every launch uses).  8 (128 x 64, a
+// quarter fewer LDS fragment bytes per MFMA) compiles, but at two workgroups per CU its 128 accumulator registers push
+// the kernel past the 256-VGPR cap: 500 bytes of scratch per lane, 15.3 vs 13.9 ms per step — not instantiated.
+template <typename T, int TW, int TH, int BN, int HB, int TMv = 4>
 struct HgCfg {
   static constexpr int CH = Elem<T>::CH;
   static constexpr int CK = 8 * CH;                  // channels per 128-byte chunk (64 bf16 / 32 f32)
   static constexpr int TPIX = TW * TH;
   static constexpr int HW_ = TW + 2, HH = TH + 2, HPIX = HW_ * HH;
-  static constexpr int WMN = TPIX / 64, WNN = BN / 64;
+  static constexpr int WMN = TPIX / (16 * TMv), WNN = BN / 64;
   static constexpr int NWAVE = WMN * WNN;
   static constexpr int NT = 64 * NWAVE;
   static constexpr int HALO = HPIX * 128;
@@ -61,11 +64,11 @@ struct HgCfg {
 
 // BNR: instantiate the fused BatchNorm-backward reduction of the epilogue (ConvArgs::bnr_*); kept out of the plain
 // variant so that its register allocation does not pay for it
-template <typename T, int TW, int TH, int BN, int HB, bool BNR>
-__global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const ConvArgs a) {  // 64 * (TPIX/64) * (BN/64) threads
-  using Cfg = HgCfg<T, TW, TH, BN, HB>;
+template <typename T, int TW, int TH, int BN, int HB, bool BNR, int TMv = 4>
+__global__ __launch_bounds__(TW * TH * BN / (16 * TMv), 2) void conv3x3_hg_kernel(const ConvArgs a) {  // 64 * (TPIX/(16 TM)) * (BN/64) threads
+  using Cfg = HgCfg<T, TW, TH, BN, HB, TMv>;
   constexpr int CH = Cfg::CH, CK = Cfg::CK, HW_ = Cfg::HW_, HPIX = Cfg::HPIX, NT = Cfg::NT, TPIX = Cfg::TPIX;
-  constexpr int TM = 4, TN = 4, MTX = TW / 16;
+  constexpr int TM = TMv, TN = 4, MTX = TW / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* halo0 = smem;
   unsigned char* bt0 = smem + HB * Cfg::HALO;
@@ -162,18 +165,18 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const 
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // Fragment addresses, precomputed: the halo swizzle depends on the column only, so a tap (r,s) is
-  // acol[s][i] + r * (HW_*128); the h = 1 half is the same address with bit 6 flipped (chunk + 4).
-  unsigned acol[3][TM], bfo[TN];
+  // Fragment addresses: the halo swizzle depends on the column only, and (px & 7) does not see the multiple-of-16 column
+  // offset of an M tile, so three lane-dependent bases (one per column shift sx) serve every M tile, tap row and chunk
+  // half through compile-time offsets: tap (r, sx), M tile g -> abase[sx] + ((g / MTX + r) * HW_ + (g % MTX) * 16) * 128,
+  // the h = 1 half is the same address with bit 6 flipped (chunk + 4).
+  unsigned abase[3], bfo[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int g = wm * 4 + i;
-    const int py = g / MTX, px = (g % MTX) * 16 + lr;
-#pragma unroll
-    for (int sx = 0; sx < 3; ++sx) acol[sx][i] = (unsigned)((py * HW_ + px + sx) * 128 + ((lq ^ ((px + sx) & 7)) << 4));
-  }
+  for (int sx = 0; sx < 3; ++sx) abase[sx] = (unsigned)((lr + sx) * 128 + ((lq ^ ((lr + sx) & 7)) << 4));
 #pragma unroll
   for (int j = 0; j < TN; ++j) bfo[j] = (unsigned)sw_off(wn * 64 + j * 16 + lr, lq);
+
+  static_assert(TM % MTX == 0, "a wave's M tiles start at a tile-row boundary");
+  const unsigned wbase = (unsigned)((wm * TM / MTX) * HW_ * 128);   // first tile row of this wave
 
   halo_load(0);
   b_load(0, 0);
@@ -198,15 +201,24 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const 
       const unsigned char* hbr = hb + r * (HW_ * 128);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        u32x4 af[TM], bfr[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(hbr + (acol[sx][i] ^ (h << 6)));
+        u32x4 bfr[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(bb + (bfo[j] ^ (h << 6)));
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i0 = 0; i0 < TM; i0 += 4) {   // four M tiles at a time: 16 A-fragment registers live, not 4 * TM
+          u32x4 af[4];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) GMma<T>::run(af[i], bfr[j], acc[i][j]);
+          for (int i = 0; i < 4; ++i) {
+            const int g = wm * TM + i0 + i;   // wm enters as a run-time multiple of the per-wave row stride below
+            (void)g;
+            af[i] = *reinterpret_cast<const u32x4*>(hbr + wbase + (((i0 + i) / MTX) * HW_ + ((i0 + i) % MTX) * 16) * 128 +
+                                                    (abase[sx] ^ (h << 6)));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) GMma<T>::run(af[i], bfr[j], acc[i0 + i][j]);
+        }
       }
       b_store(cur ^ 1);
       if (tap == 8) {
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const 
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int g = wm * 4 + i;
+        const int g = wm * TM + i;
         const int row = (g / MTX) * TW + (g % MTX) * 16 + lq * 4 + rr;  // tile-local pixel
         T v = Elem<T>::from_f(fmaf(acc[i][q][rr], osc, bias));
         const float vf = Elem<T>::to_f(v);
@@ -273,10 +285,10 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hg_kernel(const 
 
 int g_hg_variant = -1;  // tuning override (FLAIR_HG_VARIANT): 0 = 256 px x 8 waves, 1 = 128 px x 4 waves x 2 WG/CU
 
-template <typename T, int TW, int TH, int BN, int HB, bool BNR>
+template <typename T, int TW, int TH, int BN, int HB, bool BNR, int TMv = 4>
 int launch_hg_cfg_b(const ConvArgs& a, hipStream_t s) {
-  using Cfg = HgCfg<T, TW, TH, BN, HB>;
-  auto kern = conv3x3_hg_kernel<T, TW, TH, BN, HB, BNR>;
+  using Cfg = HgCfg<T, TW, TH, BN, HB, TMv>;
+  auto kern = conv3x3_hg_kernel<T, TW, TH, BN, HB, BNR, TMv>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
@@ -302,9 +314,9 @@ int launch_hg_cfg_b(const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <typename T, int TW, int TH, int BN, int HB>
+template <typename T, int TW, int TH, int BN, int HB, int TMv = 4>
 int launch_hg_cfg(const ConvArgs& a, hipStream_t s) {
-  return a.bnr_partial ? launch_hg_cfg_b<T, TW, TH, BN, HB, true>(a, s) : launch_hg_cfg_b<T, TW, TH, BN, HB, false>(a, s);
+  return a.bnr_partial ? launch_hg_cfg_b<T, TW, TH, BN, HB, true, TMv>(a, s) : launch_hg_cfg_b<T, TW, TH, BN, HB, false, TMv>(a, s);
 }
 
 }  // namespace
