@@ -253,6 +253,240 @@ int launch_halo_cfg_l(const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent variant for the single-chunk layers (16 or 32 input channels from one source, one column block): the
+// kernel above spends its life in phases — load halo + weights, barrier, MFMAs, barrier, store — and the HBM phase of one
+// workgroup overlaps the LDS/MFMA phase of its neighbours only by luck.  Here a workgroup keeps the weights in LDS for
+// the whole launch, walks many tiles, prefetches the next tile's halo into registers while the current one is
+// multiplied, and keeps its BatchNorm partial statistics in registers ([2][Cout][gridDim.x] partials).
+template <typename T, int CK, int BN>
+struct HaloPCfg {
+  using B = HaloCfg<T, CK, BN>;
+  static constexpr int WOFF = 0, HOFF = (B::WBYTES + 255) / 256 * 256, COFF = HOFF + (B::HALO + 255) / 256 * 256;
+  static constexpr int SOFF = COFF + (B::CT + 255) / 256 * 256;
+  static constexpr int SMEM = SOFF + B::STATS;
+};
+
+template <typename T, int CK, int BN, bool LZ>
+__global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, int ntiles) {
+  using Cfg = HaloCfg<T, CK, BN>;
+  using PC = HaloPCfg<T, CK, BN>;
+  constexpr int CH = Cfg::CH, KF = Cfg::KF, CPP = Cfg::CPP, TN = BN / 16, TM = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem + PC::WOFF;
+  unsigned char* halo = smem + PC::HOFF;
+  unsigned char* ct = smem + PC::COFF;
+  float* st = reinterpret_cast<float*>(smem + PC::SOFF);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int H = a.Hout, W = a.Wout;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  const T* __restrict__ src0 = (const T*)a.src0;
+  const T* __restrict__ wp = (const T*)a.w;
+  const int Hs = a.up0 ? (H >> 1) : H, Ws = a.up0 ? (W >> 1) : W;
+  const int sh = a.up0 ? 1 : 0;
+
+  // weights: all nine taps of the one chunk, once (+ the zero tail of every row)
+  if constexpr (Cfg::KW > 9 * CK) {
+    constexpr int PADC = (Cfg::KW - 9 * CK) / CH;
+    for (int it = t; it < BN * PADC; it += 256) {
+      const int row = it / PADC, pc = it - row * PADC;
+      *reinterpret_cast<u32x4*>(wl + row * Cfg::WROW + (9 * CK + pc * CH) * (int)sizeof(T)) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  for (int it = t; it < BN * 9 * CPP; it += 256) {
+    const int row = it / (9 * CPP), rem = it - row * (9 * CPP);
+    const int tap = rem / CPP, ch = rem - tap * CPP;
+    *reinterpret_cast<u32x4*>(wl + row * Cfg::WROW + rem * 16) =
+        *reinterpret_cast<const u32x4*>(wp + (long)row * a.Kpad + tap * CK + ch * CH);
+  }
+  float lsc[CH], lsh[CH];   // lazy BN + ReLU of the producing unit: a thread always stages the same chunk column
+  if (LZ && a.in_scale) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      lsc[e] = a.in_scale[(t % CPP) * CH + e];
+      lsh[e] = a.in_shift[(t % CPP) * CH + e];
+    }
+  }
+  float osc[TN], obi[TN], s1[TN], s2[TN];
+#pragma unroll
+  for (int q = 0; q < TN; ++q) {
+    const int col = q * 16 + lr;
+    const bool cok = col < a.Cout;
+    osc[q] = (a.oscale && cok) ? a.oscale[col] : 1.f;
+    obi[q] = ((a.bias && cok) ? a.bias[col] : 0.f) + ((a.oshift && cok) ? a.oshift[col] : 0.f);
+    s1[q] = 0.f; s2[q] = 0.f;
+  }
+
+  u32x4 hreg[Cfg::HITEMS];
+  unsigned hbits = 0;
+  auto halo_load = [&](int tile) {
+    const bool tok = tile < ntiles;
+    const int tl = tok ? tile : 0;
+    const int n = tl / (tiles_x * tiles_y);
+    const int trem = tl - n * tiles_x * tiles_y;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    unsigned hb = 0;
+#pragma unroll
+    for (int k = 0; k < Cfg::HITEMS; ++k) {
+      const int it = t + 256 * k;
+      const int hp = it / CPP, ch = it - hp * CPP;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = tok && (it < HPIX * CPP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+      const unsigned off = ok ? (unsigned)(((n * Hs + (iy >> sh)) * Ws + (ix >> sh)) * CK + ch * CH) : 0u;
+      hreg[k] = *reinterpret_cast<const u32x4*>(src0 + off);
+      hb |= (ok ? 1u : 0u) << k;
+    }
+    hbits = hb;
+  };
+  auto halo_store = [&]() {
+#pragma unroll
+    for (int k = 0; k < Cfg::HITEMS; ++k) {
+      const int it = t + 256 * k;
+      if (it < HPIX * CPP) {
+        const int hp = it / CPP, ch = it - hp * CPP;
+        const u32x4 hv = (LZ && a.in_scale) ? chunk_bn_relu<T>(hreg[k], lsc, lsh) : hreg[k];
+        *reinterpret_cast<u32x4*>(halo + hp * Cfg::PSTRIDE + ch * 16) = hv & (0u - ((hbits >> k) & 1u));
+      }
+    }
+  };
+
+  halo_load(blockIdx.x);
+  halo_store();
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    halo_load(tile + gridDim.x);          // next tile rides in registers through this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < Cfg::KW / KF; ++j) {
+      const int k0 = j * KF + lq * CH;
+      int tap = k0 / CK;
+      const int c = k0 - tap * CK;
+      tap = tap > 8 ? 8 : tap;  // padded K: the weights there are zero, any valid address will do
+      const int r = tap / 3, s = tap - 3 * r;
+      u32x4 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int py = 2 * wave + (i >> 1), px = (i & 1) * 16 + lr;
+        af[i] = *reinterpret_cast<const u32x4*>(halo + ((py + r) * HW_ + px + s) * Cfg::PSTRIDE + c * (int)sizeof(T));
+      }
+#pragma unroll
+      for (int q = 0; q < TN; ++q)
+        bfr[q] = *reinterpret_cast<const u32x4*>(wl + (q * 16 + lr) * Cfg::WROW + k0 * (int)sizeof(T));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < TN; ++q) HMma<T>::run(af[i], bfr[q], acc[i][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < TN; ++q) {
+      const int col = q * 16 + lr;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = (2 * wave + (i >> 1)) * TW + (i & 1) * 16 + lq * 4 + rr;  // tile-local pixel
+          const T v = Elem<T>::from_f(fmaf(acc[i][q][rr], osc[q], obi[q]));
+          const float vf = Elem<T>::to_f(v);
+          s1[q] += vf;
+          s2[q] = fmaf(vf, vf, s2[q]);
+          *reinterpret_cast<T*>(ct + row * Cfg::CLD + col * (int)sizeof(T)) = v;
+        }
+      }
+    }
+    __syncthreads();   // every wave is done with the halo, the C tile is complete
+    halo_store();
+    {
+      const int n = tile / (tiles_x * tiles_y);
+      const int trem = tile - n * tiles_x * tiles_y;
+      const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+      store_tile<T, TW, TH * TW, BN, 256, Cfg::CLD>(a, ct, n, y0, x0, 0, t);
+      if (a.out_nchw) {
+        const long HWp = (long)H * W;
+        for (int idx = t; idx < TH * TW * BN; idx += 256) {
+          const int nl = idx / (TH * TW), ml = idx - nl * (TH * TW);
+          const int py = ml / TW, px = ml - py * TW;
+          if (nl < a.Cout)
+            a.out_nchw[((long)n * a.Cout + nl) * HWp + (long)(y0 + py) * W + x0 + px] =
+                Elem<T>::to_f(*reinterpret_cast<const T*>(ct + ml * Cfg::CLD + nl * (int)sizeof(T)));
+        }
+      }
+    }
+    __syncthreads();   // next halo visible, C tile free
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int q = 0; q < TN; ++q) {
+      s1[q] += __shfl_xor(s1[q], 16); s1[q] += __shfl_xor(s1[q], 32);
+      s2[q] += __shfl_xor(s2[q], 16); s2[q] += __shfl_xor(s2[q], 32);
+      if (lq == 0) {
+        st[(wave * BN + q * 16 + lr) * 2 + 0] = s1[q];
+        st[(wave * BN + q * 16 + lr) * 2 + 1] = s2[q];
+      }
+    }
+    __syncthreads();
+    if (t < BN && t < a.Cout) {
+      float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { x1 += st[(w * BN + t) * 2]; x2 += st[(w * BN + t) * 2 + 1]; }
+      a.stats[(long)t * gridDim.x + blockIdx.x] = x1;
+      a.stats[((long)a.Cout + t) * gridDim.x + blockIdx.x] = x2;
+    }
+  }
+}
+
+template <typename T, int CK, int BN>
+int halo_p_blocks(const ConvArgs& a) {
+  const long ntiles = (long)a.N * a.Hout * a.Wout / (TH * TW);
+  int per_cu = (160 * 1024) / HaloPCfg<T, CK, BN>::SMEM;
+  per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+  const long cap = 256L * per_cu;
+  return (int)(ntiles < cap ? ntiles : cap);
+}
+
+template <typename T, int CK, int BN, bool LZ>
+int launch_halo_p_l(const ConvArgs& a, hipStream_t s) {
+  using PC = HaloPCfg<T, CK, BN>;
+  auto kern = conv3x3_halo_p_kernel<T, CK, BN, LZ>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long M = (long)a.N * a.Hout * a.Wout;
+  {
+    const double flops = 2.0 * (double)M * a.Cout * a.Kg;
+    const double bytes = ((double)M / (a.up0 ? 4 : 1) * a.C0 + (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) +
+                         (double)a.Cout * a.Kg * sizeof(T) + (a.out_nchw ? (double)M * a.Cout * 4.0 : 0.0);
+    static const char* names[2][2] = {{"conv3x3_halo_f32_ck16", "conv3x3_halo_f32_ck32"}, {"conv3x3_halo_bf16_ck16", "conv3x3_halo_bf16_ck32"}};
+    ProfScope ps(names[sizeof(T) == 2][CK == 32], flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(halo_p_blocks<T, CK, BN>(a)), dim3(256), PC::SMEM, s, a, (int)(M / (TH * TW)));
+  }
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int CK, int BN>
+int launch_halo_p(const ConvArgs& a, hipStream_t s) {
+  return a.in_scale ? launch_halo_p_l<T, CK, BN, true>(a, s) : launch_halo_p_l<T, CK, BN, false>(a, s);
+}
+
+// single chunk from one source, one column block
+bool halo_persistent(const ConvArgs& a) {
+  static const int on = [] { const char* e = getenv("FLAIR_HALO_PERSIST"); return e ? atoi(e) : 1; }();
+  const int Cin = a.C0 + a.C1;
+  const int want = on == 2 ? 16 : 32;   // 16-channel inputs are purely HBM-bound and do better with more, short-lived workgroups
+  return on && a.C1 == 0 && (Cin == 32 || Cin == want) && a.Cout <= 32;
+}
+
 template <typename T, int CK, int BN>
 int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   return a.in_scale ? launch_halo_cfg_l<T, CK, BN, true>(a, s) : launch_halo_cfg_l<T, CK, BN, false>(a, s);
@@ -271,11 +505,30 @@ bool conv_halo_applicable(const ConvArgs& a) {
   return Cin <= 128 && a.Cout <= 128 && (a.Cout <= 32 || Cin <= 32);
 }
 
-int conv_halo_grid_rows(const ConvArgs& a) { return (int)((long)a.N * a.Hout * a.Wout / (TH * TW)); }
+template <typename T>
+static int halo_rows_t(const ConvArgs& a) {
+  const int Cin = a.C0 + a.C1;
+  const bool n16 = a.Cout <= 16;
+  if (Cin == 16) return n16 ? halo_p_blocks<T, 16, 16>(a) : halo_p_blocks<T, 16, 32>(a);
+  return n16 ? halo_p_blocks<T, 32, 16>(a) : halo_p_blocks<T, 32, 32>(a);
+}
+
+int conv_halo_grid_rows(int dtype, const ConvArgs& a) {
+  if (halo_persistent(a)) return dtype == DT_F32 ? halo_rows_t<float>(a) : halo_rows_t<bf16_t>(a);
+  return (int)((long)a.N * a.Hout * a.Wout / (TH * TW));
+}
 
 int launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s) {
   const int Cin = a.C0 + a.C1;
   const bool n16 = a.Cout <= 16;
+  if (halo_persistent(a)) {
+    if (dtype == DT_F32) {
+      if (Cin == 16) return n16 ? launch_halo_p<float, 16, 16>(a, s) : launch_halo_p<float, 16, 32>(a, s);
+      return n16 ? launch_halo_p<float, 32, 16>(a, s) : launch_halo_p<float, 32, 32>(a, s);
+    }
+    if (Cin == 16) return n16 ? launch_halo_p<bf16_t, 16, 16>(a, s) : launch_halo_p<bf16_t, 16, 32>(a, s);
+    return n16 ? launch_halo_p<bf16_t, 32, 16>(a, s) : launch_halo_p<bf16_t, 32, 32>(a, s);
+  }
   if (dtype == DT_F32) {
     if (Cin == 16) return n16 ? launch_halo_cfg<float, 16, 16>(a, s) : launch_halo_cfg<float, 16, 32>(a, s);
     return n16 ? launch_halo_cfg<float, 32, 16>(a, s) : launch_halo_cfg<float, 32, 32>(a, s);

@@ -338,7 +338,7 @@ static inline int pick_bn(int cout) { return cout >= 128 ? 128 : cout >= 64 ? 64
 static inline int pick_bm(int cout) { return cout >= 64 ? 128 : 256; }
 
 bool conv_halo_applicable(const ConvArgs& a);           // conv_halo.hip
-int conv_halo_grid_rows(const ConvArgs& a);
+int conv_halo_grid_rows(int dtype, const ConvArgs& a);
 int launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s);
 bool conv_stem_applicable(int dtype, const ConvArgs& a);  // stem.hip
 int conv_stem_grid_rows(const ConvArgs& a);
@@ -366,10 +366,10 @@ bool conv_mfma_bound(int dtype, const ConvArgs& a) {
 }
 
 int conv_grid_rows(int dtype, const ConvArgs& a) {
-  if (a.in_scale && conv_halo_applicable(a)) return conv_halo_grid_rows(a);
+  if (a.in_scale && conv_halo_applicable(a)) return conv_halo_grid_rows(dtype, a);
   if (conv_stem_applicable(dtype, a)) return conv_stem_grid_rows(a);
   if (conv_hg_applicable(dtype, a)) return conv_hg_grid_rows(dtype, a);
-  if (conv_halo_applicable(a)) return conv_halo_grid_rows(a);
+  if (conv_halo_applicable(a)) return conv_halo_grid_rows(dtype, a);
   return cdiv((long)a.N * a.Hout * a.Wout, pick_bm(a.Cout));
 }
 
