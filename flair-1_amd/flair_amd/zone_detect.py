@@ -160,3 +160,92 @@ class ZoneDetector:
             L.check(L.lib().flair_detect_stitch(L.ptr(logits), B, self.n_classes, self.S, self.margin, mode, L.ptr(tiles),
                                                 L.ptr(out), Hr, Wr, L.stream()), "flair_detect_stitch")
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Tile bookkeeping of the overlap strategies (src/zone_detect/test/tiles.py, test/pixel_operation.py): host integer /
+# float64 arithmetic on small maps, mirrored for callers that schedule overlapping windows themselves.  Pinned by
+# tests/golden/tiling_reference.json (the reference functions, imported directly).
+
+def out_of_bounds(bigbox, box):
+    """tiles.py:17-27 — per coordinate of ``box``: is it outside ANY of the four bounds of ``bigbox``
+    (left, right, bottom, top), compared as the reference does (every coordinate against all four)."""
+    left, right, bottom, top = bigbox
+    return [bool(c < left or c > right or c < bottom or c > top) for c in box]
+
+
+def get_tile_coord(start: int, end: int, limit: int, patch_size: int, stride: int):
+    """tiles.py:30-51 — tile origins along one axis that intersect [start, end): multiples of ``stride`` below ``end``,
+    the ones that would pass ``limit`` pulled back to limit - patch_size (ascending; the reference's order is a set's)."""
+    last = limit - patch_size
+    if last < 0:
+        return []
+    origins = {min(i, last) if i + patch_size > limit else i for i in range(0, end, stride)}
+    return sorted(o for o in origins if o + patch_size > start and o < end)
+
+
+def _axis_cover(lo: int, hi: int, limit: int, patch_size: int, stride: int):
+    """how many tiles of one axis cover each position of [lo, hi)"""
+    import numpy as np
+    n = np.zeros(hi - lo, dtype=np.int64)
+    for o in get_tile_coord(lo, hi, limit, patch_size, stride):
+        a, b = max(o, lo), min(o + patch_size, hi)
+        if b > a:
+            n[a - lo:b - lo] += 1
+    return n
+
+
+def patch_overlap(image_size, patch_size: int, query_bounds, stride: int):
+    """tiles.py:54-94 — number of tiles covering every pixel of the query rectangle (x_min, x_max, y_min, y_max); the
+    tiles form a grid, so the count is the outer product of the per-axis coverages."""
+    import numpy as np
+    x_min, x_max, y_min, y_max = query_bounds
+    cx = _axis_cover(x_min, x_max, image_size[0], patch_size, stride)
+    cy = _axis_cover(y_min, y_max, image_size[1], patch_size, stride)
+    return np.outer(cy, cx).astype(np.uint8)
+
+
+def patch_weights(patch_size: int, sigma: float, mode: str):
+    """tiles.py:97-108 — weight of a pixel by its Chebyshev distance d to the patch centre:
+    'gaussian': exp(-d / d_max^2) / (2 sigma^2); anything else: exp(-d / d_max * sigma)."""
+    import numpy as np
+    c = patch_size // 2
+    ax = np.abs(np.arange(patch_size) - c)
+    dist = np.maximum(ax[:, None], ax[None, :])
+    if mode == "gaussian":
+        return np.exp(-dist / dist.max() ** 2) / (2 * sigma ** 2)
+    return np.exp(-dist / dist.max() * sigma)
+
+
+def total_weights(image_size, patch_size: int, query_bounds, stride: int, track_steps: bool = False):
+    """tiles.py:111-168 — sum over the tiles intersecting the query of their 'exp' patch weights (sigma 0.5), float32."""
+    import numpy as np
+    x_min, x_max, y_min, y_max = query_bounds
+    acc = np.zeros((y_max - y_min, x_max - x_min), dtype=np.float32)
+    w = patch_weights(patch_size, sigma=0.5, mode="exp")
+    steps = []
+    for ty in get_tile_coord(y_min, y_max, image_size[1], patch_size, stride):
+        ya, yb = max(ty, y_min), min(ty + patch_size, y_max)
+        for tx in get_tile_coord(x_min, x_max, image_size[0], patch_size, stride):
+            xa, xb = max(tx, x_min), min(tx + patch_size, x_max)
+            if yb > ya and xb > xa:
+                acc[ya - y_min:yb - y_min, xa - x_min:xb - x_min] += w[ya - ty:yb - ty, xa - tx:xb - tx]
+                if track_steps:
+                    steps.append(acc.copy())
+    return acc, steps
+
+
+def slice_pixels(img_size, patch_size: int, margin: int, stride: int):
+    """pixel_operation.py:1-60 — margin-cropped boxes (x_min, x_max, y_min, y_max) of a regular grid with step
+    ``stride``, plus a last row / column / corner flush with the image edge when the grid does not end there."""
+    x_size, y_size = img_size
+    k = patch_size - 2 * margin
+
+    def axis(size):
+        starts = [o for o in range(0, size + 1, stride) if o + k <= size]
+        if size - k > 0 and (size - k) % stride != 0:
+            starts.append(size - k)
+        return starts
+
+    xs, ys = axis(x_size), axis(y_size)
+    return sorted({(x, x + k, y, y + k) for y in ys for x in xs})

@@ -9,6 +9,8 @@ Executed from the reference, unchanged, loaded by path:
                                  predict_dataset.__getitem__
   * src/flair/tasks_utils.py     parsing_metadata (45-d metadata encoding)
   * src/zone_detect/dataset.py   convert ('argmax', 'class_prob')
+  * src/zone_detect/test/tiles.py, test/pixel_operation.py   (import without any stand-in) get_stride, out_of_bounds,
+                                 get_tile_coord, patch_overlap, patch_weights, total_weights, slice_pixels
 
 Absent third-party packages are replaced in ``sys.modules`` by stand-ins that carry NO arithmetic of the
 path: rasterio (``open`` hands back arrays this script made; nothing is decoded), geopandas, albumentations,
@@ -160,6 +162,38 @@ def golden_convert(zd):
     print("convert:", am.shape, cp.shape, am_tie[0].ravel())
 
 
+def golden_tiling(tiles, pixop):
+    cases = [
+        {"img_size": [5, 5], "patch_size": 3, "margin": 0, "stride": 2, "query": [0, 5, 0, 5]},      # the reference's toy
+        {"img_size": [10, 10], "patch_size": 4, "margin": 0, "stride": 2, "query": [0, 10, 0, 10]},
+        {"img_size": [10, 10], "patch_size": 4, "margin": 1, "stride": 3, "query": [2, 9, 1, 7]},
+        {"img_size": [64, 48], "patch_size": 16, "margin": 2, "stride": 8, "query": [5, 40, 7, 33]},
+        {"img_size": [33, 70], "patch_size": 16, "margin": 4, "stride": 12, "query": [0, 33, 16, 70]},
+    ]
+    out = []
+    for c in cases:
+        size, P, m, st, q = tuple(c["img_size"]), c["patch_size"], c["margin"], c["stride"], c["query"]
+        tw, _ = tiles.total_weights(size, P, q, st)
+        out.append({**c,
+                    "patch_overlap": tiles.patch_overlap(size, P, q, st).tolist(),
+                    "total_weights": np.asarray(tw, dtype=np.float64).tolist(),
+                    "tile_coord_x": sorted(tiles.get_tile_coord(q[0], q[1], size[0], P, st)),
+                    "slice_pixels": [list(t) for t in pixop.slice_pixels(size, P, m, st)]})
+    extra = {
+        "patch_weights_exp_7": tiles.patch_weights(7, 0.5, "exp").tolist(),
+        "patch_weights_gauss_8": tiles.patch_weights(8, 0.5, "gaussian").tolist(),
+        "get_stride_default": tiles.get_stride({"img_pixels_detection": 512, "margin": 128}),
+        "get_stride_overlap": tiles.get_stride({"img_pixels_detection": 512, "margin": 128, "overlap_strat": True,
+                                                "strategies": {"tiling": {"stride_range": [0.25, 0.5, 0.75]}}}),
+        "out_of_bounds": [[list(b), list(x), tiles.out_of_bounds(list(b), list(x))]
+                          for b, x in (((0, 10, 0, 10), (0, 5, 0, 5)), ((0, 10, 0, 10), (-1, 5, 2, 11)),
+                                       ((100.0, 200.0, 50.0, 80.0), (120.0, 130.0, 60.0, 70.0)))],
+    }
+    with open(os.path.join(HERE, "tiling_reference.json"), "w") as f:
+        json.dump({"cases": out, **extra}, f)
+    print("tiling:", len(out), "cases")
+
+
 if __name__ == "__main__":
     _install_stubs()
     sys.path.insert(0, REF)  # the reference imports itself as `src.flair...`
@@ -169,3 +203,5 @@ if __name__ == "__main__":
     golden_metadata_encoding(tu)
     zd = _load("ref_zone_detect_dataset", "src/zone_detect/dataset.py")
     golden_convert(zd)
+    golden_tiling(_load("ref_zone_detect_tiles", "src/zone_detect/test/tiles.py"),
+                  _load("ref_zone_detect_pixop", "src/zone_detect/test/pixel_operation.py"))

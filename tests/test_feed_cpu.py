@@ -149,3 +149,28 @@ def test_zone_detect_tile_grid_owns_each_pixel_once_like_sequential_writes(W, H,
     assert (count == 1).all() and (mine == last).all()
     with pytest.raises(ValueError):
         tile_grid((P - 2 * m - 1, H), P, m)
+
+
+def test_tiling_helpers_match_reference(golden_dir):
+    """get_stride / out_of_bounds / get_tile_coord / patch_overlap / patch_weights / total_weights / slice_pixels against
+    the reference functions themselves (imported directly by tests/golden/make_golden_feed.py)."""
+    from flair_amd import zone_detect as Z
+    g = json.load(open(os.path.join(golden_dir, "tiling_reference.json")))
+    assert Z.get_stride({"img_pixels_detection": 512, "margin": 128}) == g["get_stride_default"]
+    assert Z.get_stride({"img_pixels_detection": 512, "margin": 128, "overlap_strat": True,
+                         "strategies": {"tiling": {"stride_range": [0.25, 0.5, 0.75]}}}) == g["get_stride_overlap"]
+    for big, box, want in g["out_of_bounds"]:
+        assert Z.out_of_bounds(big, box) == want
+    assert np.array_equal(Z.patch_weights(7, 0.5, "exp"), np.array(g["patch_weights_exp_7"]))
+    assert np.array_equal(Z.patch_weights(8, 0.5, "gaussian"), np.array(g["patch_weights_gauss_8"]))
+    for c in g["cases"]:
+        size, P, m, st, q = tuple(c["img_size"]), c["patch_size"], c["margin"], c["stride"], c["query"]
+        assert Z.get_tile_coord(q[0], q[1], size[0], P, st) == c["tile_coord_x"]
+        po = Z.patch_overlap(size, P, q, st)
+        assert po.dtype == np.uint8 and np.array_equal(po, np.array(c["patch_overlap"]))
+        tw, steps = Z.total_weights(size, P, q, st)
+        assert tw.dtype == np.float32 and steps == []
+        assert np.abs(tw.astype(np.float64) - np.array(c["total_weights"])).max() < 1e-6   # float32 sums, order of tiles
+        assert [list(t) for t in Z.slice_pixels(size, P, m, st)] == c["slice_pixels"]
+    toy = g["cases"][0]   # the reference's own 5x5 / patch 3 / stride 2 example: centre pixel seen by all four tiles
+    assert np.array(toy["patch_overlap"])[2, 2] == 4
