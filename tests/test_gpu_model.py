@@ -371,3 +371,50 @@ def test_nhwc_logits_head_paths_equal_the_nchw_ones(dev, dtype):
     hip.eval()
     with torch.no_grad():
         assert torch.equal(tr.predict(x), ops.softmax_argmax(hip(x).float().contiguous(), want="u8"))
+
+
+def test_config4_train_step_metadata_weighted_d4(dev):
+    """19 classes with the YAML weights (four of them zero), metadata fusion through MetadataMLP
+    (dropout off: eval() on the MLP only, so the comparison does not depend on an RNG stream), D4 augmentation and
+    'custom' normalisation on the device feed — one training step against the oracle on the same batch."""
+    import flair_amd
+    from flair_amd.data_feed import TileFeed, pack_d4
+    from oracle import unet_resnet34 as om
+    C, B = 19, 2
+    cfg = _config(5, CLASSES19, use_metadata=True)
+    torch.manual_seed(3)
+    hip = flair_amd.FLAIR_ModelFactory(cfg, compute_dtype="f32")
+    ref = om.seeded_model(5, C, 11)
+    hip.seg_model.load_state_dict(ref.state_dict(), strict=True)
+    mlp = flair_amd.MetadataMLP()
+    mlp.load_state_dict(hip.enc.state_dict())
+    hip = hip.to(dev).train()
+    hip.enc.eval()
+    ref.train(); mlp.eval()
+    g = torch.Generator().manual_seed(21)
+    img_u8 = torch.randint(0, 256, (B, 5, 512, 512), dtype=torch.uint8, generator=g)
+    raw = torch.randint(0, C + 2, (B, 512, 512), dtype=torch.uint8, generator=g)
+    mtd = torch.rand(B, 45, generator=g)
+    feed = TileFeed([1, 2, 3, 4, 5], C, "custom", [105.08, 110.87, 101.82, 106.38, 53.26], [52.17, 45.38, 44, 39.69, 79.3])
+    batch = feed(img_u8.to(dev), raw.to(dev), d4=torch.tensor([pack_d4(1, 0, 3), pack_d4(0, 1, 2)], dtype=torch.uint8), mtd=mtd)
+    weight = torch.tensor([CLASSES19[k][0] for k in CLASSES19], dtype=torch.float32)
+    crit = flair_amd.FusedCrossEntropyLoss(weight=weight).to(dev)
+    loss = crit(hip(batch["img"], batch["mtd"]), batch["msk"])
+    loss.backward()
+    # oracle: the reference's forward (model.py:57-62) on the same float batch
+    x, lab = batch["img"].cpu(), batch["msk"].cpu().long()
+    feats = ref.encoder(x)
+    enc = mlp(mtd)
+    feats[-1] = torch.add(feats[-1], enc.unsqueeze(1).unsqueeze(-1).repeat(1, 512, 1, 16))
+    logits = ref.segmentation_head(ref.decoder(*feats))
+    loss_ref = nn.functional.cross_entropy(logits, lab, weight=weight)
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) < 2e-4 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    cos = lambda a, b: float(nn.functional.cosine_similarity(a.double().flatten(), b.double().flatten(), dim=0))
+    pr = dict(ref.named_parameters())
+    cs = sorted(cos(p.grad.cpu(), pr[k].grad) for k, p in hip.seg_model.named_parameters())
+    assert cs[len(cs) // 2] > 0.9999 and cs[0] > 0.99, (cs[0], cs[len(cs) // 2])
+    # the metadata branch: gradient reaches the MLP through the row-vector add
+    pm = dict(mlp.named_parameters())
+    for k, p in hip.enc.named_parameters():
+        assert p.grad is not None and cos(p.grad.cpu(), pm[k].grad) > 0.999, k
