@@ -661,12 +661,23 @@ void UNet::encoder_bwd_impl() {
 }
 
 void UNet::stage_done(int stage) {
-  // the stage's weight gradients (side stream) are part of "done": join when somebody listens for the stage, and at the end
-  if (stage == 0 || (stage_events_ && stage_events_[stage])) side_join();
-  if (stage_events_ && stage_events_[stage] && !dry_ && !err_) {
-    hipError_t e = hipEventRecord((hipEvent_t)stage_events_[stage], s_);
-    if (e != hipSuccess) err_ = (int)e;
+  const bool listened = stage_events_ && stage_events_[stage] && !dry_ && !err_;
+  if (stage == 0) side_join();   // end of backward: everything is back on the caller's stream
+  if (!listened) return;
+  hipEvent_t ev = (hipEvent_t)stage_events_[stage];
+  if (stage != 0 && side_pending_) {
+    // The stage's weight gradients live on the side stream, the rest on s_.  Rather than stalling s_ until the side
+    // stream has caught up, let the side stream wait for s_'s current position and record the stage event THERE: it
+    // fires when both are done, and s_ runs on into the next stage.
+    hipStream_t side = wgrad_stream();   // = "side waits for everything queued on s_ so far"
+    if (side != s_) {
+      const hipError_t e = hipEventRecord(ev, side);
+      if (e != hipSuccess) err_ = (int)e;
+      return;
+    }
   }
+  const hipError_t e = hipEventRecord(ev, s_);
+  if (e != hipSuccess) err_ = (int)e;
 }
 
 int UNet::backward(const float* params, const float* dlogits_nchw, const void* dlogits_nhwc, float* grads, void* ws,
