@@ -130,6 +130,7 @@ class UNet {
   size_t fwd_top_ = 0;      // arena top after forward (backward scratch starts here)
   bool packed_d_ = false;
   bool lazy_ok_ = false;
+  int lazy_max_c_ = 16;    // widest unit that hands out a lazy activation (FLAIR_LAZY_BN=2: 32)
   // weight-gradient kernels run on an internal side stream, forked from / joined to the caller's stream with events, so
   // that their tails overlap the BatchNorm / data-gradient chain of the following units (FLAIR_WGRAD_STREAM=0: off)
   hipStream_t side_ = nullptr;

@@ -311,7 +311,7 @@ int UNet::run_unit(int ci, int bi, const Act& in0, const Act& in1, bool up0, boo
   // The 16-channel decoder units (block 4: 45 % of all BN-apply bytes) feed only small-channel halo kernels,
   // which can apply BN + ReLU while staging their input: skip the activation pass and hand out the pre-BN tensor.
   const bool lazy = lazy_ok_ && training_ && materialize && relu && res_unit < 0 && !res.p && c.R == 3 && c.stride == 1 &&
-                    c.Cout_p <= 16 && (Ho % 8) == 0 && (Wo % 32) == 0;
+                    c.Cout_p <= lazy_max_c_ && (Ho % 8) == 0 && (Wo % 32) == 0;
   if (lazy) {
     u.out = u.y;
     u.out.lz_scale = u.scale; u.out.lz_shift = u.shift;
@@ -400,6 +400,7 @@ int UNet::forward(const float* params, float* buffers, const float* x_nchw, floa
   fwd_common_begin(params, buffers, B, H, W, training);
   static const int lazy_env = [] { const char* e = getenv("FLAIR_LAZY_BN"); return e ? atoi(e) : 1; }();
   lazy_ok_ = lazy_env != 0;
+  lazy_max_c_ = lazy_env >= 2 ? 32 : 16;
   pack_forward_weights();
   encoder_fwd_impl(x_nchw);
   decoder_fwd_impl();
