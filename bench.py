@@ -221,7 +221,9 @@ def main():
                                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                    "launches_per_step": d["launches"], "avg_launch_us": round(per_launch_s * 1e6, 2),
                                    "share_of_kernel_time": round(d["ms"] / tot, 3)}
+            # sum over BOTH streams (weight gradients run beside the BN / data-gradient chain): exceeds ms_per_step
             res["kernel_time_ms_per_step"] = round(tot, 3)
+            res["kernel_time_note"] = "sum of per-kernel HIP-event times over two overlapping streams"
             if args.kernels:
                 for r in prof:
                     tf = r["flops"] / (r["ms"] / 1e3) / 1e12 if r["ms"] > 0 else 0
