@@ -418,3 +418,24 @@ def test_config4_train_step_metadata_weighted_d4(dev):
     pm = dict(mlp.named_parameters())
     for k, p in hip.enc.named_parameters():
         assert p.grad is not None and cos(p.grad.cpu(), pm[k].grad) > 0.999, k
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_training_step_is_bit_reproducible(dev, dtype):
+    """No float atomics anywhere and fixed-order two-stage reductions: the same step from the same weights gives the same
+    bits — loss, every gradient, BN running statistics — also with the weight-gradient kernels on their own stream."""
+    import flair_amd
+    ref, a = _pair(5, 13, 5, dev, dtype)
+    _, b = _pair(5, 13, 5, dev, dtype)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 5, 256, 256, generator=g).to(dev)
+    lab = torch.randint(0, 13, (4, 256, 256), generator=g).to(torch.uint8).to(dev)
+    out = []
+    for m in (a, b, a):
+        tr = flair_amd.SegTrainer(m.train(), lr=0.0)
+        loss = tr.train_step(x, lab)
+        torch.cuda.synchronize()
+        out.append((loss.item(), tr.grads.clone(), m.flat_buffers().clone()))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][1], out[2][1])   # and again on the first model (lr = 0: weights unchanged)
+    assert torch.equal(out[0][2], out[1][2])
