@@ -439,3 +439,37 @@ def test_training_step_is_bit_reproducible(dev, dtype):
     assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
     assert torch.equal(out[0][1], out[2][1])   # and again on the first model (lr = 0: weights unchanged)
     assert torch.equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_full_size_step_properties(dev, dtype):
+    """BASELINE configuration (32 x 5 x 512 x 512, 13 classes), checked through size-independent properties:
+    a batch made of the same 16 tiles twice gives pairwise identical masks (every per-pixel reduction has a fixed order
+    that does not depend on where the tile sits in the batch), the confusion matrix counts every pixel exactly once in
+    the row of its label and the column of its prediction, and the mean loss equals that of the 16-tile batch.  In fp32
+    the BatchNorm running statistics and the gradient of the doubled batch also equal the 16-tile ones up to summation
+    grouping; in bf16 ulp-level differences of the BN coefficients are amplified through 46 BatchNorm backward passes
+    (cosine ~0.95), so only the exact properties are asserted there."""
+    import flair_amd
+    _, m = _pair(5, 13, 2022, dev, dtype)
+    g = torch.Generator().manual_seed(3)
+    x16 = torch.randn(16, 5, 512, 512, generator=g)
+    lab16 = torch.randint(0, 13, (16, 512, 512), generator=g).to(torch.uint8)
+    x, lab = torch.cat([x16, x16]).to(dev), torch.cat([lab16, lab16]).to(dev)
+    tr = flair_amd.SegTrainer(m.train(), lr=0.0)
+    loss32 = tr.train_step(x, lab).item()
+    preds, cm, g32, buf32 = tr._preds.clone(), tr.confmat.clone(), tr.grads.clone(), m.flat_buffers().clone()
+    assert torch.equal(preds[:16], preds[16:])
+    assert int(cm.sum()) == 32 * 512 * 512
+    assert torch.equal(cm.sum(1), torch.bincount(lab.flatten().long(), minlength=13))
+    assert torch.equal(cm.sum(0), torch.bincount(preds.flatten().long(), minlength=13))
+    del tr
+    _, m2 = _pair(5, 13, 2022, dev, dtype)
+    tr2 = flair_amd.SegTrainer(m2.train(), lr=0.0)
+    loss16 = tr2.train_step(x[:16].contiguous(), lab[:16].contiguous()).item()
+    assert abs(loss32 - loss16) < 1e-5 * abs(loss16)
+    if dtype == "f32":
+        assert (tr2._preds == preds[:16]).float().mean() > 0.999
+        assert (buf32 - m2.flat_buffers()).abs().max() < 1e-4
+        cos = torch.nn.functional.cosine_similarity(g32.double(), tr2.grads.double(), dim=0).item()
+        assert cos > 0.999 and abs(float(g32.norm() / tr2.grads.norm()) - 1) < 5e-3, cos
