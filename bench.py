@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark of the FLAIR-1 segmentation hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or
+started plainly — then this process only SPAWNS the N ranks (one per GPU, RCCL over xGMI) and never touches a GPU
+itself; it exits with the worst child exit code and rank 0's JSON line is the output.
 
 One "step" = one pass of the hot path over one batch of synthetic tiles already resident in HBM:
 U-Net/ResNet34 forward -> fused CE/argmax/confusion-matrix head -> backward -> (RCCL gradient all-reduce,
@@ -106,6 +110,45 @@ def cpu_baseline(batch, size, classes, iters, budget_s=25.0):
                       f"{torch.get_num_threads()} threads, {dt:.1f} s"}
 
 
+def spawn_ranks(n, cmd, env=None, timeout=None):
+    """Start `cmd` n times as ranks 0..n-1 of one node (what torch.distributed.run / Lightning's DDP launcher does for the
+    reference, src/flair/tasks.py:83-88) and wait.  Rank 0 inherits stdout; the other ranks' stdout goes to stderr.
+    Returns the worst exit code.  The caller must not have initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                 "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    procs = []
+    for r in range(n):
+        e = dict(base)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        procs.append(subprocess.Popen(cmd, env=e, stdout=None if r == 0 else sys.stderr))
+    t_end = None if timeout is None else time.time() + timeout
+    worst = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in alive:       # one rank failed: the others would wait in a collective for ever
+                    q.terminate()
+        if alive:
+            if t_end is not None and time.time() > t_end:
+                for q in alive:
+                    q.kill()
+                worst = worst or 124
+            time.sleep(0.05)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,11 +167,18 @@ def main():
                     help="rehearse the RCCL gradient exchange (events, side stream, buckets) with a single rank")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain start: become the launcher.  device_count() does not initialise the GPU on this image.
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible on this node", file=sys.stderr)
+            raise SystemExit(2)
+        raise SystemExit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_exchange:

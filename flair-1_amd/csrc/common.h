@@ -139,6 +139,8 @@ struct ConvArgs {
   const float* bnr_shift;
   float* bnr_partial;
   int bnr_C;
+  // diagnostic builds only (FLAIR_HG_STAMP): per-workgroup s_memtime stamps [gridDim.x][8], written by thread 0
+  unsigned long long* dbg;
 };
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s);

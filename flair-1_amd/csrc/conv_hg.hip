@@ -14,6 +14,7 @@
 #include "common.h"
 #include "prof.h"
 #include "tile_store.h"
+#include "tune.h"
 
 namespace flair {
 namespace {
@@ -283,6 +284,352 @@ __global__ __launch_bounds__(TW * TH * BN / (16 * TMv), 2) void conv3x3_hg_kerne
   store_tile<T, TW, TPIX, BN, NT, Cfg::CLD, BNR>(a, ct, n, y0, x0, n0, t, tile, ntiles);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round-2 structure: the weight tile never passes through registers.  Each wave streams its share of the [BN][128 B]
+// tile of (chunk, tap) with LDS-DMA (global_load_lds_dwordx4: 1 KiB = 8 rows per wave-instruction, the XOR swizzle applied
+// on the per-lane SOURCE address, the LDS image stays lane-linear — cdna_hip_programming.md §5.4 rule 21) into a ring of
+// NS slots, NS - 1 taps ahead; a counted s_waitcnt vmcnt(N) + raw s_barrier per tap leaves the younger tiles in
+// flight across the barrier.  The 32 KB per tap and CU of ds_write_b128 (half of the LDS cycles of the register-staged
+// kernel above) and the breg[] registers are gone.  The halo still goes through registers once per chunk: that is where
+// the lazy BatchNorm + ReLU of the producing unit is applied (LAZY), so the normalised activation is never written.
+// Accumulation order per output element is unchanged (chunk, tap, half), so results equal the kernel above bit for bit.
+void* g_debug_buffer = nullptr;   // flair_debug_buffer(): stamps of the next halo-GEMM launches (diagnostics)
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T, int TW, int TH, int BN, int HB, int NS>
+struct HgdCfg {
+  static constexpr int CH = Elem<T>::CH;
+  static constexpr int CK = 8 * CH;
+  static constexpr int TPIX = TW * TH;
+  static constexpr int HW_ = TW + 2, HH = TH + 2, HPIX = HW_ * HH;
+  static constexpr int WMN = TPIX / 64, WNN = BN / 64;
+  static constexpr int NWAVE = WMN * WNN;
+  static constexpr int NT = 64 * NWAVE;
+  static constexpr int HALO = HPIX * 128;
+  static constexpr int BTILE = BN * 128;
+  static constexpr int CLD = BN * (int)sizeof(T) + 16;
+  static constexpr int CT = TPIX * CLD;
+  static constexpr int STAGES = HB * HALO + NS * BTILE;
+  static constexpr int MAIN = STAGES > CT ? STAGES : CT;
+  static constexpr int STATS = WMN * BN * 2 * 4;
+  static constexpr int SMEM = MAIN + STATS;
+  static constexpr int HITEMS = (HPIX * 8 + NT - 1) / NT;
+  static constexpr int DPW = BTILE / (1024 * NWAVE);   // LDS-DMA instructions per wave and weight tile
+  static constexpr int D = NS - 1;                      // prefetch distance in taps
+  static_assert(BTILE % (1024 * NWAVE) == 0, "every wave streams whole 1 KiB pieces");
+  static_assert(D >= 1 && D <= 3, "ring depth");
+};
+
+// s_waitcnt vmcnt(n) lgkmcnt(0), n a run-time (wave-uniform) value out of a small set
+__device__ __forceinline__ void wait_vm_lgkm0(int n) {
+#define FLAIR_VM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)" ::: "memory"); break;
+  switch (n) {
+    FLAIR_VM_CASE(1) FLAIR_VM_CASE(2) FLAIR_VM_CASE(3) FLAIR_VM_CASE(4) FLAIR_VM_CASE(5) FLAIR_VM_CASE(6) FLAIR_VM_CASE(7)
+    FLAIR_VM_CASE(8) FLAIR_VM_CASE(9) FLAIR_VM_CASE(10) FLAIR_VM_CASE(11) FLAIR_VM_CASE(12) FLAIR_VM_CASE(13)
+    FLAIR_VM_CASE(14) FLAIR_VM_CASE(15) FLAIR_VM_CASE(16) FLAIR_VM_CASE(17) FLAIR_VM_CASE(18) FLAIR_VM_CASE(19)
+    FLAIR_VM_CASE(20) FLAIR_VM_CASE(21) FLAIR_VM_CASE(22) FLAIR_VM_CASE(23) FLAIR_VM_CASE(24)
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+  }
+#undef FLAIR_VM_CASE
+}
+
+template <typename T, int TW, int TH, int BN, int HB, int NS, bool BNR, bool LAZY>
+__global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const ConvArgs a) {
+  using Cfg = HgdCfg<T, TW, TH, BN, HB, NS>;
+  constexpr int CH = Cfg::CH, CK = Cfg::CK, HW_ = Cfg::HW_, HPIX = Cfg::HPIX, NT = Cfg::NT, TPIX = Cfg::TPIX;
+  constexpr int TM = 4, TN = 4, MTX = TW / 16, DPW = Cfg::DPW, D = Cfg::D, HITEMS = Cfg::HITEMS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* halo0 = smem;
+  unsigned char* bt0 = smem + HB * Cfg::HALO;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wm = wave % Cfg::WMN, wn = wave / Cfg::WMN;
+  const int H = a.Hout, W = a.Wout;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  const int NB = a.Cout / BN;
+  const int nwork = gridDim.x;
+  int w = blockIdx.x;
+  if (a.xcd_remap) {   // XCD-contiguous work order (see the kernel above)
+    const int q = nwork >> 3, r = nwork & 7, xcd = w & 7;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+  }
+  const int tile = w / NB;
+  const int ntiles = nwork / NB;
+  const int n = tile / (tiles_x * tiles_y);
+  const int trem = tile - n * tiles_x * tiles_y;
+  const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+  const int n0 = (w - tile * NB) * BN;
+  const int Cin = a.C0 + a.C1;
+  const T* __restrict__ src0 = (const T*)a.src0;
+  const T* __restrict__ src1 = (const T*)a.src1;
+  const unsigned char* __restrict__ wp = (const unsigned char*)a.w;
+  const int Hs0 = a.up0 ? (H >> 1) : H, Ws0 = a.up0 ? (W >> 1) : W;
+  const int nchunks = Cin / CK;
+
+  // ---- halo chunk: global -> registers (one chunk ahead), registers -> [lazy BN + ReLU] -> LDS
+  u32x4 hreg[HITEMS];
+  unsigned hbits = 0;
+  float lsc[CH], lsh[CH];
+  bool hlazy = false;
+  auto halo_load = [&](int chunk) {
+    const int cbase = chunk * CK;
+    const bool use0 = cbase < a.C0;
+    const T* __restrict__ base = use0 ? src0 : src1;
+    const int Hs = use0 ? Hs0 : H, Ws = use0 ? Ws0 : W, Cs = use0 ? a.C0 : a.C1;
+    const int sh = (use0 && a.up0) ? 1 : 0;
+    const int coff = use0 ? cbase : cbase - a.C0;
+    unsigned hb2 = 0;
+#pragma unroll
+    for (int k = 0; k < HITEMS; ++k) {
+      const int it = t + NT * k;
+      const int hp = it >> 3, ch = it & 7;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = (it < HPIX * 8) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+      const unsigned off = ok ? (unsigned)(((n * Hs + (iy >> sh)) * Ws + (ix >> sh)) * Cs + coff + ch * CH) : 0u;
+      hreg[k] = *reinterpret_cast<const u32x4*>(base + off);
+      hb2 |= (ok ? 1u : 0u) << k;
+    }
+    hbits = hb2;
+    if constexpr (LAZY) {
+      hlazy = use0 && a.in_scale != nullptr;
+      const int c0 = hlazy ? coff + (t & 7) * CH : 0;
+      const float* __restrict__ ps = hlazy ? a.in_scale : (const float*)a.w;   // any valid address when unused
+      const float* __restrict__ ph = hlazy ? a.in_shift : (const float*)a.w;
+#pragma unroll
+      for (int e = 0; e < CH; e += 4) {
+        const float4 v1 = *reinterpret_cast<const float4*>(ps + c0 + e), v2 = *reinterpret_cast<const float4*>(ph + c0 + e);
+        lsc[e] = v1.x; lsc[e + 1] = v1.y; lsc[e + 2] = v1.z; lsc[e + 3] = v1.w;
+        lsh[e] = v2.x; lsh[e + 1] = v2.y; lsh[e + 2] = v2.z; lsh[e + 3] = v2.w;
+      }
+    }
+  };
+  constexpr int HLOADS = HITEMS + (LAZY ? 2 * (CH / 4) : 0);   // vector-memory instructions of one halo_load
+  auto halo_store = [&](int buf) {
+    unsigned char* hb = halo0 + buf * Cfg::HALO;
+#pragma unroll
+    for (int k = 0; k < HITEMS; ++k) {
+      const int it = t + NT * k;
+      if (it < HPIX * 8) {
+        const int hp = it >> 3, hx = hp % HW_;
+        u32x4 v = hreg[k];
+        if constexpr (LAZY) {
+          if (hlazy) v = chunk_bn_relu<T, u32x4>(v, lsc, lsh);
+        }
+        *reinterpret_cast<u32x4*>(hb + hp * 128 + (((it & 7) ^ (hx & 7)) << 4)) = v & (0u - ((hbits >> k) & 1u));
+      }
+    }
+  };
+  // ---- weight tile of (chunk, tap): LDS-DMA, row r of the tile = cout n0 + r, physical 16-byte slot p of the row holds
+  // logical chunk p ^ (r & 7); one wave-instruction = rows 8q .. 8q+7, lane l -> row 8q + (l >> 3), slot l & 7
+  const unsigned bvo = (unsigned)(((n0 + wave * (DPW * 8) + (lane >> 3)) * a.Kpad + (((lane & 7) ^ (lane >> 3)) * CH)) * (int)sizeof(T));
+  const unsigned brow = (unsigned)(8 * a.Kpad * (int)sizeof(T));
+  auto b_dma = [&](int chunk, int tap, int slot) {
+    const unsigned char* gb = wp + (size_t)(unsigned)((tap * Cin + chunk * CK) * (int)sizeof(T));   // wave-uniform
+    unsigned char* lb = bt0 + slot * Cfg::BTILE + wave * (DPW * 1024);
+#pragma unroll
+    for (int j = 0; j < DPW; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gb + (bvo + j * brow)), (lptr_t)(lb + j * 1024), 16, 0, 0);
+  };
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  unsigned abase[3], bfo[TN];
+#pragma unroll
+  for (int sx = 0; sx < 3; ++sx) abase[sx] = (unsigned)((lr + sx) * 128 + ((lq ^ ((lr + sx) & 7)) << 4));
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bfo[j] = (unsigned)sw_off(wn * 64 + j * 16 + lr, lq);
+  static_assert(TM % MTX == 0, "a wave's M tiles start at a tile-row boundary");
+  const unsigned wbase = (unsigned)((wm * TM / MTX) * HW_ * 128);
+
+  const int nsteps = 9 * nchunks;
+  auto stamp = [&](int i) {
+    if (a.dbg && t == 0) a.dbg[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+  // Fragment reads and MFMAs are software-pipelined by hand in two register sets: set A holds half 0 of a tap (read
+  // right after the barrier that publishes its weight tile), set B half 1 (read while half 0 multiplies).
+  u32x4 afA[TM], bfA[TN], afB[TM], bfB[TN];
+  auto rd = [&](u32x4 (&af)[TM], u32x4 (&bf)[TN], const unsigned char* hbuf, int slot, int tap, int h) {
+    const unsigned char* bb = bt0 + slot * Cfg::BTILE;
+    const unsigned char* hbr = hbuf + (tap / 3) * (HW_ * 128);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(bb + (bfo[j] ^ (h << 6)));
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      af[i] = *reinterpret_cast<const u32x4*>(hbr + wbase + ((i / MTX) * HW_ + (i % MTX) * 16) * 128 + (abase[tap % 3] ^ (h << 6)));
+  };
+  auto mm = [&](const u32x4 (&af)[TM], const u32x4 (&bf)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) GMma<T>::run(af[i], bf[j], acc[i][j]);
+  };
+  // ---- prologue: halo 0, weight tiles of steps 0 .. D-1, halo 1 into registers
+  halo_load(0);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nsteps) b_dma(d / 9, d % 9, d % NS);
+  halo_store(0);
+  const bool pre1 = nchunks > 1;
+  if (pre1) halo_load(1);
+  // younger than the tile of step 0: the D-1 other tiles and (when issued) the loads of halo 1
+  wait_vm_lgkm0((D - 1) * DPW + (pre1 ? HLOADS : 0));
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  stamp(1);
+  rd(afA, bfA, halo0, 0, 0, 0);
+
+  int sb = 0;   // (9 * chunk) % NS
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const unsigned char* hb = halo0 + (HB == 2 ? (chunk & 1) : 0) * Cfg::HALO;
+    const unsigned char* hbn = halo0 + (HB == 2 ? ((chunk + 1) & 1) : 0) * Cfg::HALO;
+    const bool last = chunk == nchunks - 1;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int cur = (9 % NS == 0) ? (tap % NS) : ((sb + tap) % NS);
+      const int nxt = (9 % NS == 0) ? ((tap + 1) % NS) : ((sb + tap + 1) % NS);
+      // stream the tile of step s + D into the slot the step before this one has just released
+      {
+        const int tp = tap + D;
+        const int pc = tp >= 9 ? chunk + 1 : chunk, pt = tp >= 9 ? tp - 9 : tp;
+        const int pslot = (9 % NS == 0) ? (tp % NS) : ((sb + tp) % NS);
+        if (pc < nchunks) b_dma(pc, pt, pslot);
+      }
+      rd(afB, bfB, hb, cur, tap, 1);
+      mm(afA, bfA);
+      // ---- end of step: wait for the tile of step s + 1 (the younger ones stay in flight) and meet the other waves
+      bool halo_younger = false;   // loads of a halo chunk issued after the tile of step s + 1
+      if (tap == 8) {
+        if constexpr (HB == 2) {
+          if (!last) {   // the other halo buffer: published by this step's barrier
+            halo_store((chunk + 1) & 1);
+            if (chunk + 2 < nchunks) { halo_load(chunk + 2); halo_younger = true; }
+          }
+        }
+      } else if (tap <= D - 2) {
+        halo_younger = chunk + 1 < nchunks;   // issued at tap 8 of the previous chunk (or in the prologue)
+      }
+      const int left = last ? 8 - tap : 9;            // steps after this one (capped)
+      const int groups = left < 1 ? 0 : ((left < D ? left : D) - 1);
+      wait_vm_lgkm0(left < 1 ? 0 : groups * DPW + (halo_younger ? HLOADS : 0));
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap < 8) {
+        rd(afA, bfA, hb, nxt, tap + 1, 0);
+        mm(afB, bfB);
+      } else if (!last) {
+        if constexpr (HB == 1) {   // single halo buffer: every wave has passed the barrier, nobody reads it any more
+          halo_store(0);
+          if (chunk + 2 < nchunks) halo_load(chunk + 2);
+          mm(afB, bfB);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          rd(afA, bfA, hbn, nxt, 0, 0);
+        } else {
+          rd(afA, bfA, hbn, nxt, 0, 0);
+          mm(afB, bfB);
+        }
+      } else {
+        mm(afB, bfB);
+      }
+    }
+    if (9 % NS != 0) sb = (sb + 9) % NS;
+  }
+  stamp(2);
+
+  // ------------------------------------------------------------------ epilogue (as the kernel above)
+  unsigned char* ct = smem;
+  float* st = reinterpret_cast<float*>(smem + Cfg::MAIN);
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int q = 0; q < TN; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+#pragma unroll
+  for (int q = 0; q < TN; ++q) {
+    const int col = wn * 64 + q * 16 + lr;
+    const bool cin_ok = (n0 + col) < a.Cout;
+    const float osc = (a.oscale && cin_ok) ? a.oscale[n0 + col] : 1.f;
+    const float bias = ((a.bias && cin_ok) ? a.bias[n0 + col] : 0.f) + ((a.oshift && cin_ok) ? a.oshift[n0 + col] : 0.f);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int g = wm * TM + i;
+        const int row = (g / MTX) * TW + (g % MTX) * 16 + lq * 4 + rr;  // tile-local pixel
+        T v = Elem<T>::from_f(fmaf(acc[i][q][rr], osc, bias));
+        const float vf = Elem<T>::to_f(v);
+        s1[q] += vf;
+        s2[q] += vf * vf;
+        *reinterpret_cast<T*>(ct + row * Cfg::CLD + col * (int)sizeof(T)) = v;
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int q = 0; q < TN; ++q) {
+      s1[q] += __shfl_xor(s1[q], 16); s1[q] += __shfl_xor(s1[q], 32);
+      s2[q] += __shfl_xor(s2[q], 16); s2[q] += __shfl_xor(s2[q], 32);
+      if (lq == 0) {
+        st[(wm * BN + wn * 64 + q * 16 + lr) * 2 + 0] = s1[q];
+        st[(wm * BN + wn * 64 + q * 16 + lr) * 2 + 1] = s2[q];
+      }
+    }
+  }
+  __syncthreads();
+  if (a.stats && t < BN && (n0 + t) < a.Cout) {
+    float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < Cfg::WMN; ++w2) { x1 += st[(w2 * BN + t) * 2]; x2 += st[(w2 * BN + t) * 2 + 1]; }
+    a.stats[(long)(n0 + t) * ntiles + tile] = x1;
+    a.stats[((long)a.Cout + n0 + t) * ntiles + tile] = x2;
+  }
+  stamp(3);
+  store_tile<T, TW, TPIX, BN, NT, Cfg::CLD, BNR>(a, ct, n, y0, x0, n0, t, tile, ntiles);
+  stamp(4);
+}
+
+template <typename T, int TW, int TH, int BN, int HB, int NS, bool BNR, bool LAZY>
+int launch_hgd_cfg_b(const ConvArgs& a, hipStream_t s) {
+  using Cfg = HgdCfg<T, TW, TH, BN, HB, NS>;
+  auto kern = conv3x3_hgd_kernel<T, TW, TH, BN, HB, NS, BNR, LAZY>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long M = (long)a.N * a.Hout * a.Wout;
+  dim3 grid((unsigned)(M / Cfg::TPIX) * (a.Cout / BN));
+  ConvArgs b = a;
+  b.xcd_remap = tune("FLAIR_XCD_REMAP", 1);
+  b.dbg = (unsigned long long*)g_debug_buffer;
+  {
+    const double flops = 2.0 * (double)M * a.Cout * a.Kg;
+    const double bytes = ((double)M / (a.up0 ? 4 : 1) * a.C0 + (double)M * a.C1 + (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) +
+                         (double)a.Cout * a.Kg * sizeof(T);
+    static const char* names[2][2] = {{"conv3x3_hg_f32_n64", "conv3x3_hg_f32_n128"}, {"conv3x3_hg_bf16_n64", "conv3x3_hg_bf16_n128"}};
+    ProfScope ps(names[sizeof(T) == 2][BN == 128], flops, bytes, s);
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::SMEM, s, b);
+  }
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int TW, int TH, int BN, int HB, int NS>
+int launch_hgd_cfg(const ConvArgs& a, hipStream_t s) {
+  if (a.in_scale) return a.bnr_partial ? -6 : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, true>(a, s);
+  return a.bnr_partial ? launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, true, false>(a, s)
+                       : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, false>(a, s);
+}
+
 int g_hg_variant = -1;  // tuning override (FLAIR_HG_VARIANT): 0 = 256 px x 8 waves, 1 = 128 px x 4 waves x 2 WG/CU
 
 template <typename T, int TW, int TH, int BN, int HB, bool BNR, int TMv = 4>
@@ -299,8 +646,7 @@ int launch_hg_cfg_b(const ConvArgs& a, hipStream_t s) {
   dim3 grid((unsigned)(M / Cfg::TPIX) * (a.Cout / BN));
   ConvArgs b = a;
   {
-    static const int remap = [] { const char* e = getenv("FLAIR_XCD_REMAP"); return e ? atoi(e) : 1; }();
-    b.xcd_remap = remap;
+    b.xcd_remap = tune("FLAIR_XCD_REMAP", 1);
   }
   {
     const double flops = 2.0 * (double)M * a.Cout * a.Kg;
@@ -321,29 +667,34 @@ int launch_hg_cfg(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// FLAIR_HG_DMA: 0 = register-staged weight tiles (round-1 kernel), 1 = LDS-DMA ring of 3 slots + single halo buffer,
+// 2 = LDS-DMA ring of 2 slots + double halo buffer, 3 = as 1 but 128-wide layers on 16x16-pixel tiles with 8 waves (one
+// workgroup per CU, ring of 4 slots, double halo buffer) where the image tiles that way
+static int hg_dma_mode() { return tune("FLAIR_HG_DMA", 1); }
+
 // tile pixel count for this layer: 128-pixel tiles (2 workgroups per CU, de-phased barriers) unless the image
 // only tiles by 256; small layers also need the finer tiling to fill 256 CUs
 static int hg_tile_pixels(int dtype, const ConvArgs& a) {
   (void)dtype;
-  if (g_hg_variant < 0) {
-    const char* e = getenv("FLAIR_HG_VARIANT");
-    g_hg_variant = e ? atoi(e) : 1;
-  }
+  if (g_hg_variant < 0) g_hg_variant = tune("FLAIR_HG_VARIANT", 1);
   const bool can128 = (a.Wout % 16 == 0) && (a.Hout % 8 == 0);
   const bool can256 = (a.Wout % 32 == 0 && a.Hout % 8 == 0) || (a.Wout % 16 == 0 && a.Hout % 16 == 0);
   if ((a.Cout % 128) != 0) return can256 ? 256 : (can128 ? 128 : 0);  // 64-wide: 4 waves x 256 px, single halo buffer
-  if (g_hg_variant == 0 && can256) return 256;
+  if (hg_dma_mode() == 3 && a.Wout % 16 == 0 && a.Hout % 16 == 0) return 256;
+  if (hg_dma_mode() == 0 && g_hg_variant == 0 && can256) return 256;
   if (can128) return 128;
   return can256 ? 256 : 0;
 }
 
 // 3x3 / stride 1 / pad 1, >= 64 output channels (multiple of 64), input channels in whole 128-byte chunks
-// per source, NHWC output (no fp32-NCHW head here).
+// per source, NHWC output (no fp32-NCHW head here).  A lazy BatchNorm + ReLU on the input (in_scale) needs the
+// LDS-DMA kernel and applies to src0 only.
 bool conv_hg_applicable(int dtype, const ConvArgs& a) {
   const int ck = dtype == DT_F32 ? 32 : 64;
   const int Cin = a.C0 + a.C1;
   if (a.R != 3 || a.S != 3 || a.out_mul != 1 || a.in_div != 1 || a.pad != 1) return false;
-  if (a.Hout != a.Hin || a.Wout != a.Win || a.in_scale || a.out_nchw || !a.out) return false;
+  if (a.Hout != a.Hin || a.Wout != a.Win || a.out_nchw || !a.out) return false;
+  if (a.in_scale && (hg_dma_mode() == 0 || a.bnr_partial)) return false;
   if ((Cin % ck) || (a.C0 % ck) || a.Cout < 64 || (a.Cout % 64)) return false;
   return hg_tile_pixels(dtype, a) != 0;
 }
@@ -353,10 +704,24 @@ int conv_hg_grid_rows(int dtype, const ConvArgs& a) { return (int)((long)a.N * a
 template <typename T>
 static int launch_hg_t(int tp, const ConvArgs& a, hipStream_t s) {
   const bool n128 = (a.Cout % 128) == 0;
+  const int dma = hg_dma_mode();
+  if (dma == 2) {
+    if (tp == 128) return n128 ? launch_hgd_cfg<T, 16, 8, 128, 2, 2>(a, s) : launch_hgd_cfg<T, 16, 8, 64, 2, 2>(a, s);
+    if (a.Wout % 32 == 0) return n128 ? launch_hgd_cfg<T, 32, 8, 128, 1, 2>(a, s) : launch_hgd_cfg<T, 32, 8, 64, 1, 2>(a, s);
+    return n128 ? launch_hgd_cfg<T, 16, 16, 128, 1, 2>(a, s) : launch_hgd_cfg<T, 16, 16, 64, 1, 2>(a, s);
+  }
+  if (dma != 0) {
+    if (tp == 128) return n128 ? launch_hgd_cfg<T, 16, 8, 128, 1, 3>(a, s) : launch_hgd_cfg<T, 16, 8, 64, 1, 3>(a, s);
+    if (n128 && dma == 3 && a.Wout % 16 == 0 && a.Hout % 16 == 0) return launch_hgd_cfg<T, 16, 16, 128, 2, 4>(a, s);
+    if (a.Wout % 32 == 0) return n128 ? launch_hgd_cfg<T, 32, 8, 128, 1, 3>(a, s) : launch_hgd_cfg<T, 32, 8, 64, 1, 3>(a, s);
+    return n128 ? launch_hgd_cfg<T, 16, 16, 128, 1, 3>(a, s) : launch_hgd_cfg<T, 16, 16, 64, 1, 3>(a, s);
+  }
   if (tp == 128) return n128 ? launch_hg_cfg<T, 16, 8, 128, 2>(a, s) : launch_hg_cfg<T, 16, 8, 64, 2>(a, s);
   if (a.Wout % 32 == 0) return n128 ? launch_hg_cfg<T, 32, 8, 128, 2>(a, s) : launch_hg_cfg<T, 32, 8, 64, 1>(a, s);
   return n128 ? launch_hg_cfg<T, 16, 16, 128, 2>(a, s) : launch_hg_cfg<T, 16, 16, 64, 1>(a, s);
 }
+
+void set_debug_buffer(void* p) { g_debug_buffer = p; }
 
 int launch_conv_hg(int dtype, const ConvArgs& a, hipStream_t s) {
   const int tp = hg_tile_pixels(dtype, a);

@@ -134,6 +134,7 @@ class UNet {
   // weight-gradient kernels run on an internal side stream, forked from / joined to the caller's stream with events, so
   // that their tails overlap the BatchNorm / data-gradient chain of the following units (FLAIR_WGRAD_STREAM=0: off)
   hipStream_t side_ = nullptr;
+  hipStream_t note_ = nullptr;   // carries the listened-for stage events: waits for s_ and side_, blocks neither
   std::vector<hipEvent_t> fork_ev_;
   hipEvent_t join_ev_ = nullptr;
   size_t fork_next_ = 0;

@@ -126,6 +126,7 @@ UNet::~UNet() {
   for (hipEvent_t e : fork_ev_) (void)hipEventDestroy(e);
   if (join_ev_) (void)hipEventDestroy(join_ev_);
   if (side_) (void)hipStreamDestroy(side_);
+  if (note_) (void)hipStreamDestroy(note_);
 }
 
 bool UNet::side_init() {
@@ -133,7 +134,7 @@ bool UNet::side_init() {
   if (!on) return false;
   if (side_) return true;
   if (hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) != hipSuccess) { side_ = nullptr; return false; }
-  fork_ev_.resize(64);
+  fork_ev_.resize(128);
   for (auto& e : fork_ev_)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
   return hipEventCreateWithFlags(&join_ev_, hipEventDisableTiming) == hipSuccess;
@@ -667,15 +668,22 @@ void UNet::stage_done(int stage) {
   if (!listened) return;
   hipEvent_t ev = (hipEvent_t)stage_events_[stage];
   if (stage != 0 && side_pending_) {
-    // The stage's weight gradients live on the side stream, the rest on s_.  Rather than stalling s_ until the side
-    // stream has caught up, let the side stream wait for s_'s current position and record the stage event THERE: it
-    // fires when both are done, and s_ runs on into the next stage.
-    hipStream_t side = wgrad_stream();   // = "side waits for everything queued on s_ so far"
-    if (side != s_) {
-      const hipError_t e = hipEventRecord(ev, side);
+    // The stage's weight gradients live on the side stream, the rest on s_.  Neither stream may wait for the other
+    // here (that would serialise the weight-gradient tails behind the data-gradient chain six times per step): a third
+    // stream waits for the current position of both and carries the stage event, which fires when both are done.
+    if (!note_ && hipStreamCreateWithFlags(&note_, hipStreamNonBlocking) != hipSuccess) note_ = nullptr;
+    if (note_) {
+      hipEvent_t e1 = fork_ev_[fork_next_++ % fork_ev_.size()];
+      hipEvent_t e2 = fork_ev_[fork_next_++ % fork_ev_.size()];
+      hipError_t e = hipEventRecord(e1, s_);
+      if (e == hipSuccess) e = hipEventRecord(e2, side_);
+      if (e == hipSuccess) e = hipStreamWaitEvent(note_, e1, 0);
+      if (e == hipSuccess) e = hipStreamWaitEvent(note_, e2, 0);
+      if (e == hipSuccess) e = hipEventRecord(ev, note_);
       if (e != hipSuccess) err_ = (int)e;
       return;
     }
+    side_join();   // no third stream: fold the side stream back in and record on s_
   }
   const hipError_t e = hipEventRecord(ev, s_);
   if (e != hipSuccess) err_ = (int)e;

@@ -195,6 +195,13 @@ int flair_profile_stop(void);
 int flair_profile_kernel(int i, char* name, int name_cap, double* total_ms, int64_t* launches, double* flops,
                          double* bytes);
 
+/* Diagnostic tuning switch (kernel-variant A/B timing inside one process; keys are the FLAIR_* environment
+ * variables DESIGN.md lists, the environment supplies the default).  Returns 0. */
+int flair_tune_set(const char* key, int value);
+/* Diagnostic: device buffer of [workgroups][8] uint64 that the next halo-GEMM launches fill with s_memtime stamps
+ * (kernel start, main loop start, main loop end, accumulators staged, stored); NULL switches it off.  Returns 0. */
+int flair_debug_buffer(void* device_u64);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,9 @@ def read_window_np(raster: np.ndarray, bands, x: float, y: float, patch: int) ->
     return out
 
 
-def detect_raster_np(model, raster: np.ndarray, config: dict) -> np.ndarray:
+def detect_raster_np(model, raster: np.ndarray, config: dict, gap_out: np.ndarray = None) -> np.ndarray:
+    """gap_out (H, W), optional: receives the top-2 softmax probability gap of the window that owns each pixel (same
+    sequential write rule as the result) — what oracle/parity.py needs to tell a tie flip from a wrong mask."""
     P, m = config["img_pixels_detection"], config["margin"]
     norma = config["norma_task"][0]
     H, W = raster.shape[1:]
@@ -62,4 +64,8 @@ def detect_raster_np(model, raster: np.ndarray, config: dict) -> np.ndarray:
         r0, r1 = H - int(round(row["top"])), H - int(round(row["bottom"]))
         c0, c1 = int(round(row["left"])), int(round(row["right"]))
         out[:, r0:r1, c0:c1] = pred[:, :r1 - r0, :c1 - c0]
+        if gap_out is not None:
+            from . import parity
+            gp = parity.top2_gap(logits, axis=0)[m:P - m, m:P - m]
+            gap_out[r0:r1, c0:c1] = gp[:r1 - r0, :c1 - c0]
     return out

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 import socket
+import sys
+import time
 
 import pytest
 import torch
@@ -172,3 +174,34 @@ def test_product_never_touches_the_oracle():
     start = bench.index("def cpu_baseline")
     end = bench.index("\ndef ", start + 1)
     assert uses and all(start <= u < end for u in uses if "import" in bench[max(0, u - 40):u + 10] or "from" in bench[max(0, u - 10):u])
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """bench.py --gpus N started plainly becomes the launcher (the role Lightning's DDP launcher has for the reference,
+    src/flair/tasks.py:83-88): N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, worst exit code returned."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    child = ("import os,sys;open(os.path.join(sys.argv[1],'r'+os.environ['RANK']),'w').write("
+             "os.environ['LOCAL_RANK']+' '+os.environ['WORLD_SIZE']+' '+os.environ['MASTER_ADDR']+' '+os.environ['MASTER_PORT'])")
+    assert bench.spawn_ranks(3, [sys.executable, "-c", child, str(tmp_path)]) == 0
+    got = [open(os.path.join(tmp_path, f"r{r}")).read().split() for r in range(3)]
+    assert [g[0] for g in got] == ["0", "1", "2"] and all(g[1] == "3" and g[2] == "127.0.0.1" for g in got)
+    assert len({g[3] for g in got}) == 1
+    # a failing rank ends the job with its code and takes the waiting ranks down instead of hanging
+    bad = "import os,sys,time;sys.exit(7) if os.environ['RANK']=='1' else time.sleep(60)"
+    t0 = time.time()
+    assert bench.spawn_ranks(2, [sys.executable, "-c", bad], timeout=30) == 7
+    assert time.time() - t0 < 20
+
+
+def test_bench_multi_gpu_request_without_gpus_fails_cleanly():
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2 and "GPU(s) are visible" in r.stderr
