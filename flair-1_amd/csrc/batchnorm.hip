@@ -427,7 +427,7 @@ int bn_backward(int dtype, const void* dout, const void* out, const void* y, con
                 int pre_nblk, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C % ch || C / ch > 128) return -2;
-  if (pre_nblk > 0 && (out || !mscale)) return -2;  // a producer-side reduction exists for mask-from-y units only
+  if (pre_nblk > 0 && !out && !mscale) return -2;   // a producer-side reduction needs a mask source (y or out)
   const int nblk = pre_nblk > 0 ? pre_nblk : bn_bwd_blocks(rows);
   const long rpb = (rows + nblk - 1) / nblk;
   if (pre_nblk <= 0) {

@@ -132,9 +132,10 @@ struct ConvArgs {
   // optional fused first pass of the BatchNorm backward of the unit that PRODUCED this conv's input (halo-tile
   // kernels only).  `out` (the pooled part when pool_c0 > 0) is then the complete gradient dz w.r.t. that unit's
   // ReLU output; the epilogue also reads the unit's pre-BN tensor bnr_y (same shape and row stride as `out`) and
-  // leaves  sum(dz*m)  and  sum(dz*m*y),  m = [y*bnr_scale + bnr_shift > 0],  per pixel tile in
+  // leaves  sum(dz*m)  and  sum(dz*m*y),  m = [y*bnr_scale + bnr_shift > 0]  (or [bnr_out > 0]),  per pixel tile in
   // bnr_partial[2][bnr_C][gridDim.x] — what bn_bwd_reduce_kernel would compute from HBM.
   const void* bnr_y;
+  const void* bnr_out;   // optional: the unit's post-ReLU output; the mask is then out > 0 (units with a residual branch)
   const float* bnr_scale;
   const float* bnr_shift;
   float* bnr_partial;

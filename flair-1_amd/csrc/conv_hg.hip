@@ -420,6 +420,8 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
           if (hlazy) v = chunk_bn_relu<T, u32x4>(v, lsc, lsh);
         }
         *reinterpret_cast<u32x4*>(hb + hp * 128 + (((it & 7) ^ (hx & 7)) << 4)) = v & (0u - ((hbits >> k) & 1u));
+        if constexpr (LAZY) __builtin_amdgcn_sched_barrier(0);   // one item at a time: interleaved, the unpacked floats of
+                                                                  // several items push the 64-wide kernels into scratch
       }
     }
   };
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
     if (a.dbg && t == 0) a.dbg[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
+  if (a.dbg && t == 0) a.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
   // Fragment reads and MFMAs are software-pipelined by hand in two register sets: set A holds half 0 of a tap (read
   // right after the barrier that publishes its weight tile), set B half 1 (read while half 0 multiplies).
   u32x4 afA[TM], bfA[TN], afB[TM], bfB[TN];
@@ -466,11 +469,14 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
     for (int i = 0; i < TM; ++i)
       af[i] = *reinterpret_cast<const u32x4*>(hbr + wbase + ((i / MTX) * HW_ + (i % MTX) * 16) * 128 + (abase[tap % 3] ^ (h << 6)));
   };
+  // The WEIGHT fragment is the MFMA's A operand: the accumulator tile is [cout][pixel], a lane holds FOUR CONSECUTIVE
+  // OUTPUT CHANNELS of one pixel (cout 4 * lq + reg, pixel lr) — 8 contiguous bytes of the NHWC row, so the epilogue
+  // stages a 16x16 block with one ds_write_b64 per lane instead of four ds_write_b16.  Same products, same k order.
   auto mm = [&](const u32x4 (&af)[TM], const u32x4 (&bf)[TN]) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) GMma<T>::run(af[i], bf[j], acc[i][j]);
+      for (int j = 0; j < TN; ++j) GMma<T>::run(bf[j], af[i], acc[i][j]);
   };
   // ---- prologue: halo 0, weight tiles of steps 0 .. D-1, halo 1 into registers
   halo_load(0);
@@ -485,7 +491,11 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   stamp(1);
-  rd(afA, bfA, halo0, 0, 0, 0);
+  // fp32 runs the fragment reads and the (16x slower, MFMA-bound) multiplies back to back in ONE register set: the
+  // second set only costs registers there
+  // (so does the lazy-input flavour of the 64-wide tiles: 11 halo registers per lane plus the BN coefficients)
+  constexpr bool PIPE = sizeof(T) == 2 && !(LAZY && BN == 64);
+  if constexpr (PIPE) rd(afA, bfA, halo0, 0, 0, 0);
 
   int sb = 0;   // (9 * chunk) % NS
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -503,8 +513,15 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
         const int pslot = (9 % NS == 0) ? (tp % NS) : ((sb + tp) % NS);
         if (pc < nchunks) b_dma(pc, pt, pslot);
       }
-      rd(afB, bfB, hb, cur, tap, 1);
-      mm(afA, bfA);
+      if constexpr (PIPE) {
+        rd(afB, bfB, hb, cur, tap, 1);
+        mm(afA, bfA);
+      } else {
+        rd(afA, bfA, hb, cur, tap, 0);
+        mm(afA, bfA);
+        rd(afA, bfA, hb, cur, tap, 1);
+        mm(afA, bfA);
+      }
       // ---- end of step: wait for the tile of step s + 1 (the younger ones stay in flight) and meet the other waves
       bool halo_younger = false;   // loads of a halo chunk issued after the tile of step s + 1
       if (tap == 8) {
@@ -523,22 +540,24 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (tap < 8) {
-        rd(afA, bfA, hb, nxt, tap + 1, 0);
-        mm(afB, bfB);
+        if constexpr (PIPE) {
+          rd(afA, bfA, hb, nxt, tap + 1, 0);
+          mm(afB, bfB);
+        }
       } else if (!last) {
         if constexpr (HB == 1) {   // single halo buffer: every wave has passed the barrier, nobody reads it any more
           halo_store(0);
           if (chunk + 2 < nchunks) halo_load(chunk + 2);
-          mm(afB, bfB);
+          if constexpr (PIPE) mm(afB, bfB);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_sched_barrier(0);
-          rd(afA, bfA, hbn, nxt, 0, 0);
-        } else {
+          if constexpr (PIPE) rd(afA, bfA, hbn, nxt, 0, 0);
+        } else if constexpr (PIPE) {
           rd(afA, bfA, hbn, nxt, 0, 0);
           mm(afB, bfB);
         }
-      } else {
+      } else if constexpr (PIPE) {
         mm(afB, bfB);
       }
     }
@@ -546,41 +565,90 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
   }
   stamp(2);
 
-  // ------------------------------------------------------------------ epilogue (as the kernel above)
+  // ------------------------------------------------------------------ epilogue
+  // Accumulators -> T -> LDS C tile ([pixel][cout]); every wave stages its own 64 x 64 block.  The BatchNorm batch
+  // statistics of the ROUNDED outputs (sum and sum of squares per output channel over the wave's 64 pixels) come from the
+  // matrix pipe: the wave re-reads its block as MFMA B operands X ([pixel k][cout n]: transposed LDS reads) and
+  // ones * X has the column sums in every row, X^T * X the sums of squares on its diagonal (products of two bf16 values
+  // are exact in fp32; fp32 mode: the exact k-ordered FMA chain of v_mfma_f32_16x16x4_f32).  ~100 instructions per lane
+  // instead of ~500 (the epilogue is issue-bound).
   unsigned char* ct = smem;
   float* st = reinterpret_cast<float*>(smem + Cfg::MAIN);
-  float s1[TN], s2[TN];
-#pragma unroll
-  for (int q = 0; q < TN; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  const bool want_stats = a.stats != nullptr;
+  const bool affine = a.oscale != nullptr || a.bias != nullptr || a.oshift != nullptr;
 #pragma unroll
   for (int q = 0; q < TN; ++q) {
-    const int col = wn * 64 + q * 16 + lr;
-    const bool cin_ok = (n0 + col) < a.Cout;
-    const float osc = (a.oscale && cin_ok) ? a.oscale[n0 + col] : 1.f;
-    const float bias = ((a.bias && cin_ok) ? a.bias[n0 + col] : 0.f) + ((a.oshift && cin_ok) ? a.oshift[n0 + col] : 0.f);
+    const int colb = wn * 64 + q * 16 + lq * 4;   // first of this lane's four output channels
+    float osc[4], bia[4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int rr = 0; rr < 4; ++rr) { osc[rr] = 1.f; bia[rr] = 0.f; }
+    if (affine) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int g = wm * TM + i;
-        const int row = (g / MTX) * TW + (g % MTX) * 16 + lq * 4 + rr;  // tile-local pixel
-        T v = Elem<T>::from_f(fmaf(acc[i][q][rr], osc, bias));
-        const float vf = Elem<T>::to_f(v);
-        s1[q] += vf;
-        s2[q] += vf * vf;
-        *reinterpret_cast<T*>(ct + row * Cfg::CLD + col * (int)sizeof(T)) = v;
+        const int c = n0 + colb + rr;
+        const bool ok = c < a.Cout;
+        if (a.oscale && ok) osc[rr] = a.oscale[c];
+        bia[rr] = ((a.bias && ok) ? a.bias[c] : 0.f) + ((a.oshift && ok) ? a.oshift[c] : 0.f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int g = wm * TM + i;
+      const int row = (g / MTX) * TW + (g % MTX) * 16 + lr;   // tile-local pixel
+      float v[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) v[rr] = affine ? fmaf(acc[i][q][rr], osc[rr], bia[rr]) : acc[i][q][rr];
+      if constexpr (sizeof(T) == 2) {
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(ct + row * Cfg::CLD + colb * 2) = pk;
+      } else {
+        *reinterpret_cast<float4*>(ct + row * Cfg::CLD + colb * 4) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }
-  if (a.stats) {
+  if (want_stats) {   // wave-uniform: EXEC is all ones for the transposed reads
+    const unsigned char* cw = ct + (wm * 64) * Cfg::CLD + (wn * 64) * (int)sizeof(T);   // this wave's own block: no barrier needed
 #pragma unroll
     for (int q = 0; q < TN; ++q) {
-      s1[q] += __shfl_xor(s1[q], 16); s1[q] += __shfl_xor(s1[q], 32);
-      s2[q] += __shfl_xor(s2[q], 16); s2[q] += __shfl_xor(s2[q], 32);
-      if (lq == 0) {
-        st[(wm * BN + wn * 64 + q * 16 + lr) * 2 + 0] = s1[q];
-        st[(wm * BN + wn * 64 + q * 16 + lr) * 2 + 1] = s2[q];
+      f32x4_t m1 = f32x4_t{0.f, 0.f, 0.f, 0.f}, m2 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+        const int p4 = lr & 3, q4 = lr >> 2;   // lane 4 * q4 + p4 of its 16-lane group: row q4, columns 4 * p4 .. 4 * p4 + 3
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {   // 32 pixels per MFMA K step
+          const unsigned char* lo = cw + (ks * 32 + 8 * lq + q4) * Cfg::CLD + q * 32 + 8 * p4;
+          const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo));
+          const s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo + 4 * Cfg::CLD));
+          u32x4 xf;
+          xf.x = (unsigned)(unsigned short)x0[0] | ((unsigned)(unsigned short)x0[1] << 16);
+          xf.y = (unsigned)(unsigned short)x0[2] | ((unsigned)(unsigned short)x0[3] << 16);
+          xf.z = (unsigned)(unsigned short)x1[0] | ((unsigned)(unsigned short)x1[1] << 16);
+          xf.w = (unsigned)(unsigned short)x1[2] | ((unsigned)(unsigned short)x1[3] << 16);
+          const u32x4 ones = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+          GMma<T>::run(ones, xf, m1);
+          GMma<T>::run(xf, xf, m2);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {   // four pixels per MFMA K step, four steps per call
+          u32x4 xf;
+          xf.x = *reinterpret_cast<const unsigned*>(cw + ((kk + 0) * 4 + lq) * Cfg::CLD + (q * 16 + lr) * 4);
+          xf.y = *reinterpret_cast<const unsigned*>(cw + ((kk + 1) * 4 + lq) * Cfg::CLD + (q * 16 + lr) * 4);
+          xf.z = *reinterpret_cast<const unsigned*>(cw + ((kk + 2) * 4 + lq) * Cfg::CLD + (q * 16 + lr) * 4);
+          xf.w = *reinterpret_cast<const unsigned*>(cw + ((kk + 3) * 4 + lq) * Cfg::CLD + (q * 16 + lr) * 4);
+          const u32x4 ones = u32x4{0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u};
+          GMma<T>::run(ones, xf, m1);
+          GMma<T>::run(xf, xf, m2);
+        }
       }
+      // m1: every row holds the column sums -> row 0 = lanes with lq == 0, register 0.  m2: the diagonal element of
+      // column lr sits in row lr = 4 * (lr >> 2) + (lr & 3), i.e. lane group lq == lr >> 2, register lr & 3.
+      const int dr = lr & 3;
+      const float d2 = dr == 0 ? m2[0] : dr == 1 ? m2[1] : dr == 2 ? m2[2] : m2[3];
+      if (lq == 0) st[(wm * BN + wn * 64 + q * 16 + lr) * 2 + 0] = m1[0];
+      if (lq == (lr >> 2)) st[(wm * BN + wn * 64 + q * 16 + lr) * 2 + 1] = d2;
     }
   }
   __syncthreads();
@@ -594,6 +662,9 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
   stamp(3);
   store_tile<T, TW, TPIX, BN, NT, Cfg::CLD, BNR>(a, ct, n, y0, x0, n0, t, tile, ntiles);
   stamp(4);
+  if (a.dbg && t == 0) {
+    a.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 template <typename T, int TW, int TH, int BN, int HB, int NS, bool BNR, bool LAZY>
@@ -667,9 +738,9 @@ int launch_hg_cfg(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// FLAIR_HG_DMA: 0 = register-staged weight tiles (round-1 kernel), 1 = LDS-DMA ring of 3 slots + single halo buffer,
-// 2 = LDS-DMA ring of 2 slots + double halo buffer, 3 = as 1 but 128-wide layers on 16x16-pixel tiles with 8 waves (one
-// workgroup per CU, ring of 4 slots, double halo buffer) where the image tiles that way
+// FLAIR_HG_DMA: 0 = register-staged weight tiles (round-1 kernel), 1 = LDS-DMA ring of 3 slots + single halo buffer.
+// Measured and dropped (profiles/r2_hg_variants.txt): ring of 2 slots + double halo buffer (prefetch distance 1: l4 676 vs
+// 839 TFLOP/s), 16x16-pixel tiles with 8 waves and a ring of 4 (one workgroup per CU: 609-902 vs 839-933 TFLOP/s).
 static int hg_dma_mode() { return tune("FLAIR_HG_DMA", 1); }
 
 // tile pixel count for this layer: 128-pixel tiles (2 workgroups per CU, de-phased barriers) unless the image
@@ -680,7 +751,6 @@ static int hg_tile_pixels(int dtype, const ConvArgs& a) {
   const bool can128 = (a.Wout % 16 == 0) && (a.Hout % 8 == 0);
   const bool can256 = (a.Wout % 32 == 0 && a.Hout % 8 == 0) || (a.Wout % 16 == 0 && a.Hout % 16 == 0);
   if ((a.Cout % 128) != 0) return can256 ? 256 : (can128 ? 128 : 0);  // 64-wide: 4 waves x 256 px, single halo buffer
-  if (hg_dma_mode() == 3 && a.Wout % 16 == 0 && a.Hout % 16 == 0) return 256;
   if (hg_dma_mode() == 0 && g_hg_variant == 0 && can256) return 256;
   if (can128) return 128;
   return can256 ? 256 : 0;
@@ -705,14 +775,10 @@ template <typename T>
 static int launch_hg_t(int tp, const ConvArgs& a, hipStream_t s) {
   const bool n128 = (a.Cout % 128) == 0;
   const int dma = hg_dma_mode();
-  if (dma == 2) {
-    if (tp == 128) return n128 ? launch_hgd_cfg<T, 16, 8, 128, 2, 2>(a, s) : launch_hgd_cfg<T, 16, 8, 64, 2, 2>(a, s);
-    if (a.Wout % 32 == 0) return n128 ? launch_hgd_cfg<T, 32, 8, 128, 1, 2>(a, s) : launch_hgd_cfg<T, 32, 8, 64, 1, 2>(a, s);
-    return n128 ? launch_hgd_cfg<T, 16, 16, 128, 1, 2>(a, s) : launch_hgd_cfg<T, 16, 16, 64, 1, 2>(a, s);
-  }
-  if (dma != 0) {
+  // fp32 (parity mode) is MFMA-bound at 1/16 of the bf16 rate: the register-staged kernel is as fast there; the LDS-DMA
+  // kernel serves it only for a lazy BatchNorm + ReLU input
+  if (dma != 0 && (sizeof(T) == 2 || a.in_scale)) {
     if (tp == 128) return n128 ? launch_hgd_cfg<T, 16, 8, 128, 1, 3>(a, s) : launch_hgd_cfg<T, 16, 8, 64, 1, 3>(a, s);
-    if (n128 && dma == 3 && a.Wout % 16 == 0 && a.Hout % 16 == 0) return launch_hgd_cfg<T, 16, 16, 128, 2, 4>(a, s);
     if (a.Wout % 32 == 0) return n128 ? launch_hgd_cfg<T, 32, 8, 128, 1, 3>(a, s) : launch_hgd_cfg<T, 32, 8, 64, 1, 3>(a, s);
     return n128 ? launch_hgd_cfg<T, 16, 16, 128, 1, 3>(a, s) : launch_hgd_cfg<T, 16, 16, 64, 1, 3>(a, s);
   }

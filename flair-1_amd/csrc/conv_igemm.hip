@@ -366,6 +366,7 @@ bool conv_mfma_bound(int dtype, const ConvArgs& a) {
 }
 
 int conv_grid_rows(int dtype, const ConvArgs& a) {
+  if (a.in_scale && conv_hg_applicable(dtype, a)) return conv_hg_grid_rows(dtype, a);
   if (a.in_scale && conv_halo_applicable(a)) return conv_halo_grid_rows(dtype, a);
   if (conv_stem_applicable(dtype, a)) return conv_stem_grid_rows(a);
   if (conv_hg_applicable(dtype, a)) return conv_hg_grid_rows(dtype, a);
@@ -396,7 +397,8 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
   if (a.out_sub && (a.out_nchw || a.stats || a.pool_c0 > 0 || a.bnr_partial || conv_hg_applicable(dtype, a) || conv_halo_applicable(a)))
     return -6;  // sub-sampled stores exist in the gather-form epilogue only
-  if (a.in_scale) {   // lazy BN + ReLU on the input: the small-channel halo kernel is the only one that applies it
+  if (a.in_scale) {   // lazy BN + ReLU on the input: the halo-GEMM (>= 64 channels) and the small-channel halo kernel apply it
+    if (conv_hg_applicable(dtype, a)) return (a.pool_c0 > 0 || a.bnr_partial) ? -6 : launch_conv_hg(dtype, a, s);
     if (!conv_halo_applicable(a) || (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a))) return -6;
     const int ch = dtype == DT_F32 ? 4 : 8;
     // the tile epilogue stores whole 16-byte chunks: a ragged channel count needs the row padded to the next chunk

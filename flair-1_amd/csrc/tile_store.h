@@ -20,7 +20,8 @@ struct TileItems {
 // than it hides in latency: measured 3.3 -> 3.6 ms on the 128-wide halo-GEMM.)
 template <typename T, int TW, int TPIX, int BN, int NT>
 __device__ __forceinline__ void tile_bnr_prefetch(const ConvArgs& a, int n, int y0, int x0, int n0, int t,
-                                                  uint4 (&yv)[TileItems<T, TPIX, BN, NT>::ITEMS]) {
+                                                  uint4 (&yv)[TileItems<T, TPIX, BN, NT>::ITEMS],
+                                                  uint4 (&ov)[TileItems<T, TPIX, BN, NT>::ITEMS]) {
   using TI = TileItems<T, TPIX, BN, NT>;
   constexpr int CH = TI::CH, CPR = TI::CPR;
   const int H = a.Hout, W = a.Wout;
@@ -33,6 +34,7 @@ __device__ __forceinline__ void tile_bnr_prefetch(const ConvArgs& a, int n, int 
     const bool ok = idx < TPIX * CPR && nn < a.Cout;
     const long goff = ok ? ((long)(n * H + y0 + py) * W + x0 + px) * a.out_ld + nn : 0;
     yv[k] = *reinterpret_cast<const uint4*>((const T*)a.bnr_y + goff);
+    if (a.bnr_out) ov[k] = *reinterpret_cast<const uint4*>((const T*)a.bnr_out + goff);
   }
 }
 
@@ -57,13 +59,16 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
       msh[e] = nn + e < a.bnr_C ? a.bnr_shift[nn + e] : 0.f;
     }
   }
-  auto bnr_item = [&](const uint4& v, const uint4& ychunk) {   // v: the stored (rounded) gradient chunk; y at the same place
-    float d[CH], yy[CH];
+  // v: the stored (rounded) gradient chunk; y (and, for units with a residual branch, the ReLU output) at the same place
+  auto bnr_item = [&](const uint4& v, const uint4& ychunk, const uint4& ochunk) {
+    float d[CH], yy[CH], oo[CH];
     chunk_to_f<T>(v, d);
     chunk_to_f<T>(ychunk, yy);
+    if (a.bnr_out) chunk_to_f<T>(ochunk, oo);
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
-      const float dm = fmaf(yy[e], msc[e], msh[e]) > 0.f ? d[e] : 0.f;
+      const bool on = a.bnr_out ? (oo[e] > 0.f) : (fmaf(yy[e], msc[e], msh[e]) > 0.f);
+      const float dm = on ? d[e] : 0.f;
       r1[e] += dm;
       r2[e] = fmaf(dm, yy[e], r2[e]);
     }
@@ -123,7 +128,8 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
         }
         const uint4 v = f_to_chunk<T>(fa);
         *reinterpret_cast<uint4*>(dst) = v;
-        if (bnr) bnr_item(v, *reinterpret_cast<const uint4*>((const T*)a.bnr_y + (dst - out)));
+        if (bnr) bnr_item(v, *reinterpret_cast<const uint4*>((const T*)a.bnr_y + (dst - out)),
+                          a.bnr_out ? *reinterpret_cast<const uint4*>((const T*)a.bnr_out + (dst - out)) : v);
       }
     }
     if (bnr) bnr_finish();
@@ -135,8 +141,8 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
   const int cbase = a.pool_c0 > 0 ? a.pool_c0 : 0;
   const int acc = a.pool_c0 > 0 ? a.skip_accumulate : a.accumulate;
   constexpr int ITEMS = TileItems<T, TPIX, BN, NT>::ITEMS;
-  uint4 yv[ITEMS];
-  if (bnr) tile_bnr_prefetch<T, TW, TPIX, BN, NT>(a, n, y0, x0, n0, t, yv);
+  uint4 yv[ITEMS], ov[ITEMS];
+  if (bnr) tile_bnr_prefetch<T, TW, TPIX, BN, NT>(a, n, y0, x0, n0, t, yv, ov);
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const int idx = t + k * NT;
@@ -172,7 +178,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
         v = f_to_chunk<T>(fa);
       }
       *reinterpret_cast<uint4*>(dst) = v;
-      if (bnr) bnr_item(v, yv[k]);
+      if (bnr) bnr_item(v, yv[k], ov[k]);
     }
   }
   if (bnr) bnr_finish();

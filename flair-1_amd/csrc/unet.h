@@ -79,7 +79,7 @@ class UNet {
   long n_params = 0, n_buffers = 0;
   long stage_begin[8];  // flat-parameter offset where each stage starts (stage_begin[7] = n_params)
 
-  size_t workspace_bytes(int B, int H, int W, int training);
+  size_t workspace_bytes(int B, int H, int W, int training) const;   // side-effect free
 
   // stage entry points; features cross the boundary as NCHW fp32 only in the split path
   int forward(const float* params, float* buffers, const float* x_nchw, float* logits_nchw, int B, int H, int W,
@@ -153,11 +153,13 @@ class UNet {
   struct GradBuf { void* act; void* g; bool init; };
   // unit whose ReLU output is `a`, if `a` has exactly one consumer and the unit's mask comes from y; else -1
   int sole_producer(const Act& a) const;
+  int residual_producer(const Act& a) const;
   void attach_bn_reduce(ConvArgs& a, const Act& target);
   std::vector<GradBuf> gbufs_;
   void* grad_of(const Act& a, bool* accumulate);
   void* grad_peek(const Act& a);
 
+  size_t plan_bytes(int B, int H, int W, int training);   // the dry run itself (clobbers per-call state)
   void build_table();
   int add_conv(const std::string& name, int cin, int cout, int k, int stride, int pad, bool bias, int stage);
   int add_bn(const std::string& name, int c, int stage);
@@ -165,7 +167,8 @@ class UNet {
   void pack_forward_weights();
   void pack_dgrad_weights();
   int run_unit(int conv, int bn, const Act& in0, const Act& in1, bool up0, bool relu, int res_unit, const Act& res,
-               bool materialize);
+               bool materialize, int lazy_cons = -1, bool lazy_up0 = false, const Act* lazy_skip = nullptr);
+  bool lazy_into_hg(const Act& y, int cons, bool up0, const Act& skip) const;
   void encoder_fwd_impl(const float* x_nchw);
   void decoder_fwd_impl();
   void head_fwd_impl(float* logits_nchw);

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "unet.h"
+#include "tune.h"
 
 #include <string.h>
 
@@ -130,10 +131,18 @@ UNet::~UNet() {
 }
 
 bool UNet::side_init() {
-  static const int on = [] { const char* e = getenv("FLAIR_WGRAD_STREAM"); return e ? atoi(e) : 1; }();
-  if (!on) return false;
+  if (!tune("FLAIR_WGRAD_STREAM", 1)) return false;
   if (side_) return true;
-  if (hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) != hipSuccess) { side_ = nullptr; return false; }
+  // LOW priority: (a) the weight gradients are off the critical path — when both streams have workgroups to dispatch,
+  // the BatchNorm / data-gradient chain goes first; (b) a priority level has hardware queues of its own, so the side
+  // stream can never be mapped onto the caller's queue.  (HIP multiplexes streams over a few hardware queues; with RCCL's
+  // and torch's extra streams alive the round-robin put this stream on the caller's queue and the overlap was gone:
+  // +1.4 ms per step in the single-rank rehearsal of the exchange, gpurun_out/prof_exch Queue_Id column.)
+  int least = 0, greatest = 0;
+  const bool low = tune("FLAIR_SIDE_PRIO", 1) != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+  const hipError_t ce = low ? hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, least)
+                            : hipStreamCreateWithFlags(&side_, hipStreamNonBlocking);
+  if (ce != hipSuccess) { side_ = nullptr; return false; }
   fork_ev_.resize(128);
   for (auto& e : fork_ev_)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
@@ -275,8 +284,34 @@ static void fill_conv_args(ConvArgs& a, const ConvDesc& c, const Act& in0, const
   a.in_scale = in0.lz_scale; a.in_shift = in0.lz_shift;   // lazy producers never feed a concat partner (in1)
 }
 
+bool wgrad_big_applicable(int dtype, const WgradArgs& a);   // wgrad_hg.hip
+bool conv_hg_applicable(int dtype, const ConvArgs& a);      // conv_hg.hip
+
+// Can the unit producing `y` (conv + BN + ReLU, no residual) hand its PRE-BatchNorm tensor to its single consumer, the
+// 3x3 convolution `cons` (input = [up2(y) if up0] ++ skip), which then applies BN + ReLU while it stages its halo — in
+// the forward pass (halo-GEMM kernel) and again in its weight gradient (wgrad3x3_big)?
+bool UNet::lazy_into_hg(const Act& y, int cons, bool up0, const Act& skip) const {
+  if (!training_ || !tune("FLAIR_LAZY_HG", 1)) return false;
+  const ConvDesc& c = convs[cons];
+  if (c.R != 3 || c.stride != 1) return false;
+  Act in0 = y, out;
+  in0.p = reinterpret_cast<void*>(16);
+  out.N = y.N; out.H = up0 ? 2 * y.H : y.H; out.W = up0 ? 2 * y.W : y.W; out.C = c.Cout_p; out.p = reinterpret_cast<void*>(16);
+  ConvArgs a;
+  fill_conv_args(a, c, in0, skip, up0, out, reinterpret_cast<void*>(16));
+  a.in_scale = a.in_shift = reinterpret_cast<const float*>(16);
+  if (!conv_hg_applicable(dtype, a)) return false;
+  WgradArgs w;
+  memset(&w, 0, sizeof(w));
+  w.x0 = in0.p; w.x1 = skip.p; w.C0 = in0.C; w.C1 = skip.p ? skip.C : 0; w.up0 = up0 ? 1 : 0;
+  w.N = y.N; w.Hin = out.H; w.Win = out.W; w.Hout = out.H; w.Wout = out.W; w.R = 3; w.S = 3; w.stride = 1; w.pad = 1;
+  w.dy = in0.p; w.dy_ld = c.Cout_p; w.Cout = c.Cout; w.Cin_real = c.Cin;
+  w.in_scale = w.in_shift = reinterpret_cast<const float*>(16);
+  return wgrad_big_applicable(dtype, w);
+}
+
 int UNet::run_unit(int ci, int bi, const Act& in0, const Act& in1, bool up0, bool relu, int res_unit, const Act& res,
-                   bool materialize) {
+                   bool materialize, int lazy_cons, bool lazy_up0, const Act* lazy_skip) {
   const ConvDesc& c = convs[ci];
   const BnDesc& b = bns[bi];
   Unit u;
@@ -311,8 +346,14 @@ int UNet::run_unit(int ci, int bi, const Act& in0, const Act& in1, bool up0, boo
                        u.scale, u.shift, s_));
   // The 16-channel decoder units (block 4: 45 % of all BN-apply bytes) feed only small-channel halo kernels,
   // which can apply BN + ReLU while staging their input: skip the activation pass and hand out the pre-BN tensor.
-  const bool lazy = lazy_ok_ && training_ && materialize && relu && res_unit < 0 && !res.p && c.R == 3 && c.stride == 1 &&
-                    c.Cout_p <= lazy_max_c_ && (Ho % 8) == 0 && (Wo % 32) == 0;
+  // The >= 64-channel units whose single consumer is a halo-GEMM convolution do the same (conv1 of every BasicBlock,
+  // decoder conv1 / conv2 of the wide blocks): bn_act and the normalised activation tensor vanish for them.
+  const bool plain = lazy_ok_ && training_ && materialize && relu && res_unit < 0 && !res.p;
+  bool lazy = plain && c.R == 3 && c.stride == 1 && c.Cout_p <= lazy_max_c_ && (Ho % 8) == 0 && (Wo % 32) == 0;
+  if (!lazy && plain && lazy_cons >= 0) {
+    Act none_;
+    lazy = lazy_into_hg(u.y, lazy_cons, lazy_up0, lazy_skip ? *lazy_skip : none_);
+  }
   if (lazy) {
     u.out = u.y;
     u.out.lz_scale = u.scale; u.out.lz_shift = u.shift;
@@ -348,7 +389,7 @@ void UNet::encoder_fwd_impl(const float* x_nchw) {
     for (int b = 0; b < nblk[L]; ++b) {
       const bool ds = (b == 0 && L > 0);
       const int c1 = ci++, b1 = bi++, c2 = ci++, b2 = bi++;
-      int u1 = run_unit(c1, b1, x, none, false, true, -1, none, true);
+      int u1 = run_unit(c1, b1, x, none, false, true, -1, none, true, /*single consumer: conv2*/ c2);
       int ud = -1;
       if (ds) { const int cd = ci++, bd = bi++; ud = run_unit(cd, bd, x, none, false, false, -1, none, false); }
       int u2 = run_unit(c2, b2, units_[u1].out, none, false, true, ud, ds ? none : x, true);
@@ -366,8 +407,10 @@ void UNet::decoder_fwd_impl() {
   Act x = f_[5];
   for (int i = 0; i < 5; ++i) {
     const Act skip = i < 4 ? f_[4 - i] : none;
-    int u1 = run_unit(ci++, bi++, x, skip, true, true, -1, none, true);
-    int u2 = run_unit(ci++, bi++, units_[u1].out, none, false, true, -1, none, true);
+    const Act nskip = i < 3 ? f_[3 - i] : none;   // the next block's skip partner
+    const int c1 = ci++, b1 = bi++, c2 = ci++, b2 = bi++;
+    int u1 = run_unit(c1, b1, x, skip, true, true, -1, none, true, /*single consumer: conv2*/ c2);
+    int u2 = run_unit(c2, b2, units_[u1].out, none, false, true, -1, none, true, /*next block's conv1*/ i < 4 ? c2 + 1 : -1, true, &nskip);
     x = units_[u2].out;
   }
   dec_out_ = x;
@@ -399,7 +442,7 @@ int UNet::forward(const float* params, float* buffers, const float* x_nchw, floa
   if ((H % 32) || (W % 32)) return -10;
   begin(ws, ws_bytes, s, false);
   fwd_common_begin(params, buffers, B, H, W, training);
-  static const int lazy_env = [] { const char* e = getenv("FLAIR_LAZY_BN"); return e ? atoi(e) : 1; }();
+  const int lazy_env = tune("FLAIR_LAZY_BN", 1);
   lazy_ok_ = lazy_env != 0;
   lazy_max_c_ = lazy_env >= 2 ? 32 : 16;
   pack_forward_weights();
@@ -476,16 +519,40 @@ int UNet::sole_producer(const Act& a) const {
   return -1;
 }
 
+// Residual units (conv2 of a BasicBlock: out = relu(bn(y) + x)) have two consumers inside the encoder, the next block's
+// conv1 and its identity branch.  Backward visits the identity branch first (the BN-backward apply of that block's conv2
+// writes dres) and conv1's data gradient last: an ACCUMULATING epilogue that completes the gradient.  Returns the
+// producing unit when `a` is such an activation (mask from the ReLU output), else -1.
+int UNet::residual_producer(const Act& a) const {
+  if (!a.p) return -1;
+  for (int f = 1; f <= 5; ++f)
+    if (f_[f].p == a.p) return -1;   // encoder features also feed the decoder / the next stage
+  if (a.p == dec_out_.p) return -1;
+  for (int i = 0; i < (int)units_.size(); ++i) {
+    const Unit& u = units_[i];
+    if (u.out.p != a.p) continue;
+    if (!u.relu || (u.res_unit < 0 && !u.res.p)) return -1;
+    int convs_in = 0, res_in = 0;
+    for (const Unit& v : units_) { convs_in += (v.in0.p == a.p) + (v.in1.p == a.p); res_in += (v.res.p == a.p); }
+    return (convs_in == 1 && res_in == 1) ? i : -1;
+  }
+  return -1;
+}
+
 void UNet::attach_bn_reduce(ConvArgs& a, const Act& target) {
-  const int p = sole_producer(target);
+  static const int mode = tune("FLAIR_BNR_RES", 1);   // 0: never fuse the reduction of residual units
+  int p = sole_producer(target);
+  bool from_out = false;
+  if (p < 0 && a.accumulate && mode) { p = residual_producer(target); from_out = p >= 0; }
   if (p < 0) return;
   Unit& u = units_[p];
   a.bnr_y = u.y.p; a.bnr_scale = u.scale; a.bnr_shift = u.shift; a.bnr_C = u.y.C;
+  a.bnr_out = from_out ? u.out.p : nullptr;
   a.bnr_partial = reinterpret_cast<float*>(1);  // provisional, so that the geometry check sees the request
   // only where the data-gradient kernel is MFMA-bound (the extra read of y hides under it); the small-channel
   // halo kernels are HBM-bound and gain nothing over the separate streaming reduction
-  if (a.accumulate || u.y.C != a.out_ld || !conv_tile_epilogue_ok(dtype, a) || !conv_mfma_bound(dtype, a)) {
-    a.bnr_y = nullptr; a.bnr_partial = nullptr; a.bnr_scale = a.bnr_shift = nullptr; a.bnr_C = 0;
+  if ((a.accumulate && !from_out) || u.y.C != a.out_ld || !conv_tile_epilogue_ok(dtype, a) || !conv_mfma_bound(dtype, a)) {
+    a.bnr_y = nullptr; a.bnr_out = nullptr; a.bnr_partial = nullptr; a.bnr_scale = a.bnr_shift = nullptr; a.bnr_C = 0;
     return;
   }
   const int nblk = conv_grid_rows(dtype, a);
@@ -760,8 +827,15 @@ int UNet::encoder_backward(const float* params, const float* const dfeats[5], fl
   return err_;
 }
 
-// Upper bound of the arena: dry run of the split sequence (superset of the fused one).
-size_t UNet::workspace_bytes(int B, int H, int W, int training) {
+// Upper bound of the arena: dry run of the split sequence (superset of the fused one) on a SCRATCH executor, so that
+// sizing a workspace between a training forward and its backward (an eval forward does that) leaves the recorded graph
+// of the live handle alone.
+size_t UNet::workspace_bytes(int B, int H, int W, int training) const {
+  UNet scratch(in_channels, classes, dtype);
+  return scratch.plan_bytes(B, H, W, training);
+}
+
+size_t UNet::plan_bytes(int B, int H, int W, int training) {
   begin(nullptr, 0, nullptr, true);
   fwd_common_begin(nullptr, nullptr, B, H, W, training);
   lazy_ok_ = false;   // the materialised (split) sequence is the upper bound

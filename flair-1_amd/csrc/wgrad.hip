@@ -297,6 +297,7 @@ void launch_wgrad_reduce(const float* partial, float* dw, int splits, int Cout, 
 }
 
 size_t wgrad_workspace_bytes(int dtype, const WgradArgs& a) {
+  if (a.in_scale && wgrad_big_applicable(dtype, a)) return wgrad_big_workspace_bytes(dtype, a);
   if (a.in_scale && wgrad_halo_applicable(a)) return wgrad_halo_workspace_bytes(a);
   if (wgrad_stem_applicable(dtype, a)) return wgrad_stem_workspace_bytes(a);
   if (wgrad_big_applicable(dtype, a)) return wgrad_big_workspace_bytes(dtype, a);
@@ -330,7 +331,10 @@ static int wg_launch(const WgKArgs& ka, int splits, hipStream_t s) {
 int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if ((a.C0 % ch) || (a.C1 % ch) || (a.dy_ld % ch)) return -2;
-  if (a.in_scale) return wgrad_halo_applicable(a) ? launch_wgrad_halo(dtype, a, s) : -6;  // lazy input: that kernel only
+  if (a.in_scale) {   // lazy input: the two halo-staging kernels apply it
+    if (wgrad_big_applicable(dtype, a)) return launch_wgrad_big(dtype, a, s);
+    return wgrad_halo_applicable(a) ? launch_wgrad_halo(dtype, a, s) : -6;
+  }
   if (wgrad_stem_applicable(dtype, a)) return launch_wgrad_stem(a, s);        // 7x7 stride-2 stem
   if (wgrad_big_applicable(dtype, a)) return launch_wgrad_big(dtype, a, s);  // MFMA-bound 3x3 s1 layers, >= 64 channels
   if (wgrad_halo_applicable(a)) return launch_wgrad_halo(dtype, a, s);  // HBM-bound small-channel 3x3 layers

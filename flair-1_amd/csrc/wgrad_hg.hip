@@ -70,6 +70,7 @@ struct WgBigArgs {
   const void* dy; int dy_ld; int Cout;
   float* partial;   // [gridDim.x][Cout][9*Cin] fp32
   int Kg, ntiles;
+  const float* in_scale; const float* in_shift;   // lazy BN + ReLU on x0 (WgradArgs::in_scale)
 };
 
 // KG = 1: 16*CH output channels per workgroup (256 B of dY per pixel), waves 4 x 2.
@@ -91,7 +92,9 @@ struct WgBigCfg {
   static constexpr int DITEMS = (TPIX * DCH) / NT;                // 4 | 2
 };
 
-template <typename T, int KG>
+// LZ: x0 is the PRE-BatchNorm output of the producing unit; relu(x * in_scale[c] + in_shift[c]) is applied while the halo
+// is staged (a thread always stages the same 16-byte channel chunk, so its coefficients are loaded once)
+template <typename T, int KG, bool LZ>
 __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
   using Cfg = WgBigCfg<T, KG>;
   constexpr int CH = Cfg::CH, CK = Cfg::CK, CO = Cfg::CO, COT = Cfg::COT, CIT = Cfg::CIT, DCH = Cfg::DCH;
@@ -122,6 +125,15 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
 
   u32x4 xr[Cfg::XITEMS], dr[Cfg::DITEMS];
   unsigned xm[Cfg::XITEMS];
+  float lsc[CH], lsh[CH];
+  const bool lz = LZ && use0 && a.in_scale != nullptr;
+  if constexpr (LZ) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      lsc[e] = lz ? a.in_scale[coff + (t & 7) * CH + e] : 1.f;
+      lsh[e] = lz ? a.in_shift[coff + (t & 7) * CH + e] : 0.f;
+    }
+  }
   auto load_tile = [&](int tile) {
     const bool tok = tile < a.ntiles;
     const int tl = tok ? tile : 0;
@@ -155,7 +167,13 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
 #pragma unroll
     for (int k = 0; k < Cfg::XITEMS; ++k) {
       const int it = t + NT * k;
-      if (it < HPIX * 8) *reinterpret_cast<u32x4*>(xh + (it >> 3) * Cfg::XSTRIDE + (it & 7) * 16) = xr[k] & xm[k];
+      if (it < HPIX * 8) {
+        u32x4 xv = xr[k];
+        if constexpr (LZ) {
+          if (lz) xv = chunk_bn_relu<T, u32x4>(xv, lsc, lsh);
+        }
+        *reinterpret_cast<u32x4*>(xh + (it >> 3) * Cfg::XSTRIDE + (it & 7) * 16) = xv & xm[k];
+      }
     }
 #pragma unroll
     for (int k = 0; k < Cfg::DITEMS; ++k) {
@@ -309,10 +327,10 @@ size_t wgrad_big_workspace_bytes(int dtype, const WgradArgs& a) {
   return (size_t)ns * a.Cout * 9 * (a.C0 + a.C1) * sizeof(float);
 }
 
-template <typename T, int KG>
-static int launch_big_t(const WgBigArgs& h, int nsplit, int Cin, hipStream_t s) {
+template <typename T, int KG, bool LZ>
+static int launch_big_l(const WgBigArgs& h, int nsplit, int Cin, hipStream_t s) {
   using Cfg = WgBigCfg<T, KG>;
-  auto kern = wgrad3x3_big_kernel<T, KG>;
+  auto kern = wgrad3x3_big_kernel<T, KG, LZ>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
@@ -328,6 +346,11 @@ static int launch_big_t(const WgBigArgs& h, int nsplit, int Cin, hipStream_t s) 
   return 0;
 }
 
+template <typename T, int KG>
+static int launch_big_t(const WgBigArgs& h, int nsplit, int Cin, hipStream_t s) {
+  return h.in_scale ? launch_big_l<T, KG, true>(h, nsplit, Cin, s) : launch_big_l<T, KG, false>(h, nsplit, Cin, s);
+}
+
 int launch_wgrad_big(int dtype, const WgradArgs& a, hipStream_t s) {
   int nsplit, kg;
   if (!wg_big_geom(dtype, a, nsplit, kg)) return -2;
@@ -336,6 +359,7 @@ int launch_wgrad_big(int dtype, const WgradArgs& a, hipStream_t s) {
   h.x0 = a.x0; h.x1 = a.x1; h.C0 = a.C0; h.C1 = a.C1; h.up0 = a.up0; h.N = a.N; h.H = a.Hin; h.W = a.Win;
   h.dy = a.dy; h.dy_ld = a.dy_ld; h.Cout = a.Cout; h.partial = a.partial; h.Kg = 9 * Cin;
   h.ntiles = (int)((long)a.N * a.Hin * a.Win / TPIX);
+  h.in_scale = a.in_scale; h.in_shift = a.in_shift;
   int rc;
   if (dtype == DT_F32) rc = kg == 1 ? launch_big_t<float, 1>(h, nsplit, Cin, s) : launch_big_t<float, 2>(h, nsplit, Cin, s);
   else rc = kg == 1 ? launch_big_t<bf16_t, 1>(h, nsplit, Cin, s) : launch_big_t<bf16_t, 2>(h, nsplit, Cin, s);

@@ -63,7 +63,9 @@ class MulticlassJaccardIndex(nn.Module):
     def __init__(self, num_classes, average="macro", **_):
         super().__init__()
         self.num_classes, self.average = num_classes, average
-        self.register_buffer("confmat", torch.zeros(num_classes, num_classes, dtype=torch.int64))
+        # metric STATE, not a parameter of the task: torchmetrics keeps its states out of state_dict() (persistent=False),
+        # so reference checkpoints neither contain nor expect these keys
+        self.register_buffer("confmat", torch.zeros(num_classes, num_classes, dtype=torch.int64), persistent=False)
 
     def update(self, preds, target):
         p = preds.contiguous()
@@ -105,8 +107,8 @@ class MulticlassJaccardIndex(nn.Module):
 class MeanMetric(nn.Module):
     def __init__(self, **_):
         super().__init__()
-        self.register_buffer("total", torch.zeros((), dtype=torch.float32))
-        self.register_buffer("weight", torch.zeros((), dtype=torch.float32))
+        self.register_buffer("total", torch.zeros((), dtype=torch.float32), persistent=False)   # see MulticlassJaccardIndex
+        self.register_buffer("weight", torch.zeros((), dtype=torch.float32), persistent=False)
 
     def update(self, value, weight=1.0):
         v = value.detach().float() if torch.is_tensor(value) else torch.tensor(float(value), device=self.total.device)

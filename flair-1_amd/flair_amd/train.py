@@ -143,6 +143,7 @@ class SegTrainer:
         m._c_forward(img, training=False, want_logits=False)   # logits stay NHWC in the workspace
         preds = torch.empty(B, H, W, dtype=torch.uint8, device=img.device)
         l = L.lib()
-        L.check(l.flair_softmax_argmax_nhwc(l.flair_unet_logits_nhwc(m._h), m._dt, l.flair_unet_head_ld(m._h), B, m.classes, H, W,
+        he = m._hh(False)   # eval forwards run on their own executor
+        L.check(l.flair_softmax_argmax_nhwc(l.flair_unet_logits_nhwc(he), m._dt, l.flair_unet_head_ld(he), B, m.classes, H, W,
                                             L.ptr(preds), None, None, L.stream()), "softmax_argmax_nhwc")
         return preds

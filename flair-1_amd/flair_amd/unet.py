@@ -361,11 +361,28 @@ class Unet(nn.Module):
         return self._grad_views(self._grads, prefix)
 
     # -------------------------------------------------------------------------------------------- native calls
+    def _hh(self, training):
+        """The native executor for this call: eval-mode forwards (predict, validation, ZoneDetector) run on a second
+        handle, so that one issued between a training forward and its backward — legal in PyTorch — leaves the recorded
+        training graph alone."""
+        if training:
+            return self._h
+        h = self.__dict__.get("_h_eval")
+        if h is None:
+            h = C.c_void_p()
+            L.check(L.lib().flair_unet_create(C.byref(h), self.in_channels, self.classes, self._dt), "flair_unet_create")
+            object.__setattr__(self, "_h_eval", h)
+        return h
+
     def _workspace(self, B, H, W, training):
         key = "train" if training else "eval"
-        need = L.lib().flair_unet_workspace_bytes(self._h, B, H, W, int(training))
-        if need < 0:
-            raise RuntimeError("flair_unet_workspace_bytes failed")
+        plan = self.__dict__.setdefault("_ws_need", {})
+        need = plan.get((B, H, W, bool(training)))
+        if need is None:   # the dry run walks the whole 47-conv graph on the host: once per shape, not once per step
+            need = L.lib().flair_unet_workspace_bytes(self._h, B, H, W, int(training))
+            if need < 0:
+                raise RuntimeError("flair_unet_workspace_bytes failed")
+            plan[(B, H, W, bool(training))] = need
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need or ws.device != self._flat_p.device:
             self._ws[key] = ws = torch.empty(need, dtype=torch.uint8, device=self._flat_p.device)
@@ -400,7 +417,7 @@ class Unet(nn.Module):
         B, _, H, W = x.shape
         ws = self._workspace(B, H, W, training)
         logits = torch.empty(B, self.classes, H, W, dtype=torch.float32, device=x.device) if want_logits else None
-        L.check(L.lib().flair_unet_forward(self._h, L.ptr(self._flat_p), L.ptr(self._flat_b), L.ptr(x), L.ptr(logits), B, H, W,
+        L.check(L.lib().flair_unet_forward(self._hh(training), L.ptr(self._flat_p), L.ptr(self._flat_b), L.ptr(x), L.ptr(logits), B, H, W,
                                            int(training), L.ptr(ws), ws.numel(), L.stream()), "flair_unet_forward")
         if training:
             self._fwd_id += 1
@@ -436,11 +453,13 @@ class Unet(nn.Module):
         chans = (64, 64, 128, 256, 512)
         feats = [torch.empty(B, c, H >> (i + 1), W >> (i + 1), dtype=torch.float32, device=x.device) for i, c in enumerate(chans)]
         arr = (C.c_void_p * 5)(*[f.data_ptr() for f in feats])
-        L.check(L.lib().flair_unet_encoder_forward(self._h, L.ptr(self._flat_p), L.ptr(self._flat_b), L.ptr(x), arr, B, H, W,
+        L.check(L.lib().flair_unet_encoder_forward(self._hh(training), L.ptr(self._flat_p), L.ptr(self._flat_b), L.ptr(x), arr, B, H, W,
                                                    int(training), L.ptr(ws), ws.numel(), L.stream()), "encoder_forward")
-        self._split_shape = (B, H, W)
-        self._split_ws = ws
+        # per mode: an eval-mode split forward must not disturb a training one that still awaits its backward
+        self.__dict__.setdefault("_split", {})[bool(training)] = ((B, H, W), ws)
         if training:
+            self._split_shape = (B, H, W)
+            self._split_ws = ws
             self._fwd_id += 1
             self._live_id = self._fwd_id
             self._live_ws = ws
@@ -449,23 +468,21 @@ class Unet(nn.Module):
         return feats
 
     def _c_decoder_forward(self, feats, training):
-        B, H, W = self._split_shape
-        ws = self._split_ws
+        (B, H, W), ws = self._split[bool(training)]
         feats = [f.detach().to(torch.float32).contiguous() for f in feats]
         out = torch.empty(B, 16, H, W, dtype=torch.float32, device=feats[0].device)
         arr = (C.c_void_p * 5)(*[f.data_ptr() for f in feats])
-        L.check(L.lib().flair_unet_decoder_forward(self._h, L.ptr(self._flat_p), L.ptr(self._flat_b), arr, L.ptr(out), B, H, W,
+        L.check(L.lib().flair_unet_decoder_forward(self._hh(training), L.ptr(self._flat_p), L.ptr(self._flat_b), arr, L.ptr(out), B, H, W,
                                                    int(training), L.ptr(ws), ws.numel(), L.stream()), "decoder_forward")
         if training:
             self._bump_bn(36, 46)
         return out
 
     def _c_head_forward(self, x, training):
-        B, H, W = self._split_shape
-        ws = self._split_ws
+        (B, H, W), ws = self._split[bool(training)]
         x = x.detach().to(torch.float32).contiguous()
         logits = torch.empty(B, self.classes, H, W, dtype=torch.float32, device=x.device)
-        L.check(L.lib().flair_unet_head_forward(self._h, L.ptr(self._flat_p), L.ptr(x), L.ptr(logits), B, H, W, int(training),
+        L.check(L.lib().flair_unet_head_forward(self._hh(training), L.ptr(self._flat_p), L.ptr(x), L.ptr(logits), B, H, W, int(training),
                                                 L.ptr(ws), ws.numel(), L.stream()), "head_forward")
         return logits
 
@@ -545,13 +562,14 @@ class Unet(nn.Module):
 
     def __del__(self):
         try:
-            h = self.__dict__.get("_h")
-            if h:
-                L.lib().flair_unet_destroy(h)
+            for k in ("_h", "_h_eval"):
+                h = self.__dict__.get(k)
+                if h:
+                    L.lib().flair_unet_destroy(h)
         except Exception:
             pass
 
-    _NATIVE_STATE = ("_h", "_ws", "_flat_p", "_flat_b", "_flat_n", "_grads", "_live_ws", "_split_ws")
+    _NATIVE_STATE = ("_h", "_h_eval", "_ws_need", "_split", "_ws", "_flat_p", "_flat_b", "_flat_n", "_grads", "_live_ws", "_split_ws")
 
     def __getstate__(self):
         d = dict(self.__dict__)

@@ -9,8 +9,10 @@ same ``PRED_<name>`` LZW TIFFs through PIL as the reference does (writer.py:45-5
 """
 from __future__ import annotations
 
+import atexit
 import queue
 import threading
+import weakref
 from pathlib import Path
 
 import torch
@@ -66,9 +68,12 @@ class predictionwriter(_Base):
         if not preds.is_cuda:
             raise RuntimeError("predictionwriter expects device predictions (no CPU path)")
         if self._worker is None:
-            self._worker = threading.Thread(target=self._run, daemon=True)
+            # not a daemon: tiles still queued when the interpreter exits must reach the disk (atexit drains the queue)
+            self._worker = threading.Thread(target=self._run, daemon=False)
             self._worker.start()
             self._copy_stream = torch.cuda.Stream(device=preds.device)
+            ref = weakref.ref(self)
+            atexit.register(lambda: (ref() is not None) and ref()._close_quietly())
         u8 = preds if preds.dtype == torch.uint8 else preds.to(torch.uint8)  # astype('uint8'), on the device
         host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
         self._copy_stream.wait_stream(torch.cuda.current_stream())
@@ -85,15 +90,40 @@ class predictionwriter(_Base):
         batch_indices = getattr(getattr(trainer, "predict_loop", None), "current_batch_indices", None)
         self.write_on_batch_end(trainer, pl_module, outputs, batch_indices, batch, batch_idx, dataloader_idx)
 
-    def flush(self):
-        """Block until every queued tile is on disk (call at predict end)."""
-        self._q.join()
-        if self._error is not None:
-            raise self._error
+    # Lightning calls these at the end of trainer.predict(); the reference reads the PRED_* files right after it
+    # (main.py:238-242), so every queued tile must be on disk and a worker-side failure must surface here.
+    def on_predict_epoch_end(self, trainer=None, pl_module=None, *args, **kwargs):
+        self.flush()
 
-    def close(self):
+    def on_predict_end(self, trainer=None, pl_module=None):
+        self.close()
+
+    def teardown(self, trainer=None, pl_module=None, stage=None):
+        self.close()
+
+    def flush(self):
+        """Block until every queued tile is on disk; re-raise what the worker caught."""
         if self._worker is not None:
-            self.flush()
+            self._q.join()
+        if self._error is not None:
+            err, self._error = self._error, None
+            raise err
+
+    def _stop_worker(self):
+        if self._worker is not None:
+            self._q.join()
             self._q.put(None)
             self._worker.join()
             self._worker = None
+
+    def close(self):
+        self._stop_worker()
+        if self._error is not None:
+            err, self._error = self._error, None
+            raise err
+
+    def _close_quietly(self):
+        try:
+            self._stop_worker()
+        except Exception:  # noqa: BLE001
+            pass

@@ -36,5 +36,12 @@ for name, H, C0, C1, up0, Cout in SHAPES:
     tot = s[:, 4] - s[:, 0]
     med = lambda v: float(v.median())
     nch = (C0 + C1) // 64
+    rt0, rt1 = s[:, 5], s[:, 6]
+    span_us = (float(rt1.max()) - float(rt0.min())) / 100.0
+    clk = float(((s[:, 4] - s[:, 0]) / (rt1 - rt0)).median()) * 100.0   # MHz
+    starts = ((rt0 - rt0.min()) / 100.0)
+    late = int((starts > 0.25 * span_us).sum())
+    print(f"    realtime: kernel span {span_us:6.1f} us, median WG lifetime {float((rt1 - rt0).median()) / 100.0:6.1f} us, in-kernel clock {clk:6.0f} MHz, "
+          f"WGs starting after 25% of the span: {late}")
     print(f"{name:20s} {n} WGs  total {med(tot):8.0f} cyc | prologue {med(d[0]):7.0f} | loop {med(d[1]):8.0f} = {med(d[1]) / (9 * nch):6.0f}/tap "
           f"| stage {med(d[2]):6.0f} | store {med(d[3]):6.0f} | span(max end - min start) {float(s[:, 4].max() - s[:, 0].min()):9.0f}", flush=True)

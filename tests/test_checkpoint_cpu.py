@@ -96,3 +96,30 @@ def test_resume_restores_optimizer_and_scheduler(tmp_path):
     assert b.scheduler.state_dict()["cooldown_counter"] == a.scheduler.state_dict()["cooldown_counter"]
     assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))
     assert os.path.getsize(path) > 90e6  # 24.4 M fp32 parameters
+
+
+def test_metric_state_stays_out_of_checkpoints(tmp_path):
+    """torchmetrics states are non-persistent, so the reference's .ckpt files hold the model and criterion.weight only;
+    a checkpoint saved after setup('fit') must resume strictly into a fresh module and carry no metric keys."""
+    import torch.nn as nn
+    import flair_amd
+    from flair_amd import checkpoint as ck
+    C = 13
+
+    def make():
+        model = flair_amd.FLAIR_ModelFactory(_config(C), compute_dtype="f32")
+        task = flair_amd.segmentation_task_training(model=model, class_infos=_classes(C), optimizer=None, scheduler=None,
+                                                    criterion=nn.CrossEntropyLoss(weight=torch.ones(C)), use_metadata=False)
+        return task
+
+    a = make()
+    a.setup("fit")
+    keys = set(a.state_dict())
+    want = {"model.seg_model." + k for k in om.seeded_model(5, C, seed=1).state_dict()} | {"criterion.weight"}
+    assert keys == want, sorted(keys ^ want)[:8]
+    path = str(tmp_path / "after_setup.ckpt")
+    ck.save_checkpoint(path, a, epoch=1, global_step=7)
+    b = make()
+    ck.resume(path, b)          # strict=True inside: fails on any unexpected / missing key
+    b.setup("fit")
+    ck.resume(path, b)          # and the reverse order: a reference-style .ckpt strict-loaded after setup()

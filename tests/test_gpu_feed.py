@@ -199,7 +199,11 @@ def test_metrics_and_writer_end_to_end(dev, tmp_path):
     for i in range(0, n, 2):
         batch = {"preds": torch.from_numpy(preds[i:i + 2]).to(dev), "id": [f"/data/x/img/IMG_{j:06d}.tif" for j in (i, i + 1)]}
         w.on_predict_batch_end(None, None, batch, batch, i // 2)
-    w.close()
+    # only the hook sequence Lightning drives (tasks.py:125-142 builds the callback locally, main.py:238-242 reads the files
+    # right after trainer.predict): no explicit flush()/close() by the caller
+    w.on_predict_epoch_end(None, None)
+    w.on_predict_end(None, None)
+    assert w._worker is None
     for i in range(n):
         assert np.array_equal(np.asarray(Image.open(out_dir / f"PRED_IMG_{i:06d}.tif")), preds[i].astype(np.uint8))
     with pytest.raises(RuntimeError):

@@ -471,3 +471,89 @@ def test_full_size_step_properties(dev, dtype):
         assert (buf32 - m2.flat_buffers()).abs().max() < 1e-4
         cos = torch.nn.functional.cosine_similarity(g32.double(), tr2.grads.double(), dim=0).item()
         assert cos > 0.999 and abs(float(g32.norm() / tr2.grads.norm()) - 1) < 5e-3, cos
+
+
+def test_eval_forward_between_training_forward_and_backward(dev):
+    """Legal in PyTorch (validation / predict on the model between loss computation and backward): eval-mode forwards run
+    on their own native executor and workspace, so the recorded training graph survives — gradients equal those of an
+    undisturbed step bit for bit."""
+    ref, hip = _pair(5, 13, 77, dev)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 5, 64, 64, generator=g).to(dev)
+    lab = torch.randint(0, 13, (2, 64, 64), generator=g).to(dev)
+    hip.train()
+
+    def grads(disturb):
+        for p in hip.parameters():
+            p.grad = None
+        hip.load_state_dict(ref.state_dict(), strict=True)   # same weights and running statistics for both runs
+        loss = nn.functional.cross_entropy(hip(x), lab)
+        if disturb:
+            hip.eval()
+            with torch.no_grad():
+                hip(torch.flip(x, dims=[3]))                  # whole-model eval forward
+                hip.predict(x[:1]) if hasattr(hip, "predict") else None
+            hip.train()
+        loss.backward()
+        return [p.grad.clone() for p in hip.parameters()]
+
+    a, b = grads(False), grads(True)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+def test_checkpoint_files_drive_the_hip_model(dev, tmp_path):
+    """f4 on the device (main.py:77-146, zone_detect/model.py:61-88): a Lightning-style .ckpt written from the ORACLE's
+    weights -> flair_amd.checkpoint.{load_checkpoint, load_model, resume} -> HIP forward == oracle forward; the 19 -> 13
+    class surgery zeroes the head (logits become exactly the zero bias) and leaves the trunk intact."""
+    import flair_amd
+    from flair_amd import checkpoint as ck
+    from flair_amd.tasks_utils import get_segmentation_module
+    from oracle import parity
+    from oracle import unet_resnet34 as om
+    C = 19
+    ref = om.seeded_model(5, C, seed=31).eval()
+    with torch.no_grad():   # non-trivial running statistics, as a trained checkpoint has
+        for m in ref.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2, generator=torch.Generator().manual_seed(1))
+                m.running_var.uniform_(0.5, 1.5, generator=torch.Generator().manual_seed(2))
+    lsd = {"model.seg_model." + k: v for k, v in ref.state_dict().items()}
+    lsd["criterion.weight"] = torch.ones(C)
+    path = str(tmp_path / "trained.ckpt")
+    torch.save({"state_dict": lsd, "epoch": 3, "global_step": 99, "optimizer_states": [], "lr_schedulers": []}, path)
+    x = torch.randn(2, 5, 96, 64, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        want = ref(x)
+    classes = {k: CLASSES19[k] for k in range(1, C + 1)}
+    cfg = dict(_config(5, classes), use_weights=True, learning_rate=0.02, paths={"ckpt_model_path": path})
+
+    def check(seg, name):
+        seg = seg.to(dev).eval()
+        with torch.no_grad():
+            got = seg(x.to(dev)).cpu()
+        assert float((got - want).abs().max()) < 1e-3 * max(1.0, float(want.abs().max()))
+        parity.assert_mask_parity(name, want.argmax(1).numpy(), got.argmax(1).numpy(), parity.top2_gap(want.numpy()),
+                                  logits_ref=want.numpy(), logits_hip=got.numpy())
+
+    # (1) main.py's path: load_checkpoint into the training task, same class count
+    task = get_segmentation_module(cfg, "train", compute_dtype="f32")
+    ck.load_checkpoint(cfg, task)
+    check(task.model.seg_model, "ckpt_load_checkpoint_c19")
+    # (2) Trainer.fit(ckpt_path=...) -> resume (strict)
+    task2 = get_segmentation_module(cfg, "train", compute_dtype="f32")
+    assert ck.resume(path, task2) == (3, 99)
+    check(task2.model.seg_model, "ckpt_resume_c19")
+    # (3) zone_detect's load_model (prefix stripping, strict load into the bare segmentation model)
+    zcfg = dict(cfg, model_weights=path)
+    check(ck.load_model(zcfg, compute_dtype="f32"), "ckpt_zone_detect_load_model_c19")
+    # (4) 19 -> 13 classes: head rows zeroed -> logits == 0 everywhere, encoder tensors untouched
+    classes13 = {k: CLASSES19[k] for k in range(1, 14)}
+    cfg13 = dict(_config(5, classes13), use_weights=True, learning_rate=0.02, paths={"ckpt_model_path": path})
+    task13 = get_segmentation_module(cfg13, "train", compute_dtype="f32")
+    ck.load_checkpoint(cfg13, task13)
+    seg13 = task13.model.seg_model.to(dev).eval()
+    with torch.no_grad():
+        lg13 = seg13(x.to(dev)).cpu()
+    assert lg13.shape == (2, 13, 96, 64) and float(lg13.abs().max()) == 0.0
+    k = "encoder.layer2.1.conv2.weight"
+    assert torch.equal(seg13.state_dict()[k].cpu(), ref.state_dict()[k])

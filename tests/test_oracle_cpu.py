@@ -131,3 +131,40 @@ def test_weighted_ce_zero_weight_classes():
     lg = logits.clone().requires_grad_(True)
     nn.functional.cross_entropy(lg, lab, weight=w).backward()
     assert np.abs(dl - lg.grad.numpy()).max() < 1e-7
+
+
+def test_encoder_restatement_matches_transformers_resnet34(golden_dir):
+    """Two-source check of the ResNet34 trunk (smp / torchvision are absent; `transformers` has an independent
+    implementation of the same network): the oracle's encoder features equal those of transformers.ResNetModel carrying
+    the oracle's weights (tests/golden/make_golden_hf_resnet.py), in eval mode and with batch statistics."""
+    import numpy as np
+    import torch
+    from oracle import unet_resnet34 as om
+    g = np.load(os.path.join(golden_dir, "hf_resnet34_features.npz"))
+    ref = om.seeded_model(5, 13, seed=int(g["seed_model"]))
+    x = torch.from_numpy(g["x"])
+    for mode in ("eval", "train"):
+        ref.train(mode == "train")
+        with torch.no_grad():
+            feats = ref.encoder(x)
+        assert len(feats) == 6 and feats[0] is x or torch.equal(feats[0], x)
+        for i in range(1, 6):
+            want = torch.from_numpy(g[f"{mode}_f{i}"])
+            assert feats[i].shape == want.shape
+            err = float((feats[i] - want).abs().max())
+            assert err <= 2e-5 * max(1.0, float(want.abs().max())), (mode, i, err)
+    # and against the live model where transformers is importable (the build container and the GPU image both have it)
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mk_hf", os.path.join(golden_dir, "make_golden_hf_resnet.py"))
+        mk = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mk)
+        hf = mk.hf_resnet34(5)
+    except Exception:  # noqa: BLE001
+        return
+    hf.load_state_dict(mk.remap(ref.state_dict()), strict=False)
+    hf.eval(); ref.eval()
+    x2 = torch.randn(1, 5, 96, 64, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        a, b = ref.encoder(x2)[1:], mk.hf_features(hf, x2)
+    assert all(float((u - v).abs().max()) <= 2e-5 * max(1.0, float(v.abs().max())) for u, v in zip(a, b))
