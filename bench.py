@@ -50,15 +50,19 @@ def collect_profile(L):
     return sorted(out, key=lambda r: -r["ms"])
 
 
+PMC_FILE = "profiles/r2_pmc_traffic.json"
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (scripts/pmc_traffic.py over rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None when no pass covers it."""
+    """(HBM bytes per launch of `kernel`, commit the PMC passes were taken at) from the committed PMC passes
+    (scripts/pmc_traffic.py over rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, regenerated with the
+    kernel profiles every round); (None, None) when no pass covers the kernel.  It is a constant of that commit, not a
+    measurement of this run: `traffic_source_commit` says how old it is."""
     try:
-        import json as _j
-        t = _j.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")))
-        return t["kernels"][kernel]["hbm_bytes_per_launch"]
+        t = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        return t["kernels"][kernel]["hbm_bytes_per_launch"], t.get("commit")
     except Exception:  # noqa: BLE001
-        return None
+        return None, None
 
 
 def host_cores():
@@ -78,36 +82,81 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("FLAIR_CPU_BASELINE_THREADS", "16"))))
 
 
-def cpu_baseline(batch, size, classes, iters, budget_s=25.0):
+def cpu_baseline(batch, size, classes, iters, budget_s=12.0, big_batch=32):
     """The reference's CPU path (torch-CPU fp32 NCHW: model.py:64 + task_module.py:65-80 + SGD), restated
-    by oracle/, timed on this host's cores on a bounded sample of the same workload."""
+    by oracle/, timed on this host's cores on bounded samples of the same workload: training steps at
+    batch 2 (BASELINE config 1; the headline `value`) and at the bench batch, forward-only (eval, no_grad) at batch 2."""
     from oracle import seg_step
     from oracle import unet_resnet34 as om
     cores = host_cores()
     torch.set_num_threads(cores)
     m = om.seeded_model(5, classes, seed=2022).train()
     g = torch.Generator().manual_seed(2022)
-    x = torch.randn(batch, 5, size, size, generator=g)
-    lab = torch.randint(0, classes, (batch, size, size), generator=g)
-    msk = torch.stack([(lab == i) for i in range(classes)], 1).float()
 
-    def one():
-        for p in m.parameters():
-            p.grad = None
-        loss, _, _ = seg_step.step_torch(m(x), msk)
-        loss.backward()
-        seg_step.sgd_step_(m.parameters(), 0.02)
+    def data(b):
+        x = torch.randn(b, 5, size, size, generator=g)
+        lab = torch.randint(0, classes, (b, size, size), generator=g)
+        return x, torch.stack([(lab == i) for i in range(classes)], 1).float()
 
-    one()  # warm-up
-    t0 = time.perf_counter()
-    done = 0
-    while done < iters and (time.perf_counter() - t0) < budget_s:
-        one()
-        done += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(batch * done / dt, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{done} train steps (fwd+CE+bwd+SGD) of batch {batch} x 5x{size}x{size}, torch-CPU fp32 oracle, "
-                      f"{torch.get_num_threads()} threads, {dt:.1f} s"}
+    def train_leg(b, max_iters, budget):
+        x, msk = data(b)
+
+        def one():
+            for p in m.parameters():
+                p.grad = None
+            loss, _, _ = seg_step.step_torch(m(x), msk)
+            loss.backward()
+            seg_step.sgd_step_(m.parameters(), 0.02)
+
+        if b <= 2:
+            one()  # warm-up
+        t0 = time.perf_counter()
+        done = 0
+        while done < max_iters and (done == 0 or (time.perf_counter() - t0) < budget):
+            one()
+            done += 1
+        return b * done / (time.perf_counter() - t0), done, time.perf_counter() - t0
+
+    v2, n2, t2 = train_leg(batch, iters, budget_s)
+    vb, nb, tb = train_leg(big_batch, 1, budget_s)      # one step of the bench batch (~10 s)
+    m.eval()
+    x, _ = data(batch)
+    with torch.no_grad():
+        m(x)
+        t0 = time.perf_counter()
+        nf = 0
+        while nf < 40 and (time.perf_counter() - t0) < budget_s * 0.6:
+            m(x)
+            nf += 1
+        tf = time.perf_counter() - t0
+    return {"value": round(v2, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{n2} train steps (fwd+CE+bwd+SGD) of batch {batch} x 5x{size}x{size}, torch-CPU fp32 oracle, "
+                      f"{torch.get_num_threads()} threads, {t2:.1f} s",
+            "train_bs%d_tiles_per_s" % big_batch: round(vb, 3), "train_bs%d_sample" % big_batch: f"{nb} step, {tb:.1f} s",
+            "inference_tiles_per_s": round(batch * nf / tf, 3), "inference_sample": f"{nf} eval forwards of batch {batch}, {tf:.1f} s"}
+
+
+def roofline_obj(prof, args, full_workload, kernel=None):
+    """The dominant kernel of a profiled step (or `kernel`): algorithmic flops (MFMA-bound) or bytes (HBM-bound) per launch
+    over its average HIP-event duration on its launch stream."""
+    tot = sum(r["ms"] for r in prof)
+    d = next((r for r in prof if r["kernel"] == kernel), prof[0]) if kernel else prof[0]
+    per_launch_s = d["ms"] / 1e3 / d["launches"]
+    if d["flops"] > 0:
+        ach = d["flops"] / d["launches"] / per_launch_s / 1e12
+        traffic, commit = pmc_traffic(d["kernel"]) if full_workload else (None, None)
+        return {"kernel": d["kernel"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.dtype],
+                "unit": "TFLOP/s", "frac": round(ach / PEAK[args.dtype], 4), "traffic": traffic,
+                "traffic_unit": f"HBM bytes/launch (PMC passes of this command, {PMC_FILE})", "traffic_source_commit": commit,
+                "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                "launches_per_step": d["launches"], "avg_launch_us": round(per_launch_s * 1e6, 2),
+                "share_of_kernel_time": round(d["ms"] / tot, 3)}
+    ach = d["bytes"] / d["launches"] / per_launch_s / 1e9
+    traffic, commit = pmc_traffic(d["kernel"]) if full_workload else (None, None)
+    return {"kernel": d["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source_commit": commit,
+            "launches_per_step": d["launches"], "avg_launch_us": round(per_launch_s * 1e6, 2),
+            "share_of_kernel_time": round(d["ms"] / tot, 3)}
 
 
 def spawn_ranks(n, cmd, env=None, timeout=None):
@@ -163,6 +212,7 @@ def main():
     ap.add_argument("--train-only", action="store_true",
                     help="skip the eval-mode inference leg (profiling runs: only train-step launches in the trace)")
     ap.add_argument("--kernels", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--no-alone", action="store_true", help="skip the extra single-stream step behind `roofline_alone`")
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearse the RCCL gradient exchange (events, side stream, buckets) with a single rank")
     args = ap.parse_args()
@@ -220,6 +270,18 @@ def main():
     prof = collect_profile(L)
     loss = float(trainer.loss.item())
 
+    full_workload = args.dtype == "bf16" and args.batch == 32 and args.size == 512
+
+    # the dominant kernel alone: one more step with the weight gradients on the caller's stream (outside the timed region)
+    prof_alone = []
+    if rank == 0 and not args.no_alone:
+        L.lib().flair_tune_set(b"FLAIR_WGRAD_STREAM", 0)
+        trainer.train_step(img, lab)
+        L.check(L.lib().flair_profile_start(4096))
+        trainer.train_step(img, lab)
+        prof_alone = collect_profile(L)
+        L.lib().flair_tune_set(b"FLAIR_WGRAD_STREAM", 1)
+
     # inference tiles/s (eval-mode forward + argmax(softmax)), same tiles
     inf_iters = 0 if args.train_only else max(3, args.steps // 2)
     for _ in range(2 if inf_iters else 0):
@@ -230,6 +292,35 @@ def main():
         trainer.predict(img)
     sync()
     dti = time.perf_counter() - t1
+    prof_inf = []
+    if inf_iters and rank == 0:
+        L.check(L.lib().flair_profile_start(4096))
+        trainer.predict(img)
+        prof_inf = collect_profile(L)
+
+    # fp32 parity mode (exact v_mfma_f32_16x16x4_f32 arithmetic, the mode the mask / logit parity is asserted in): same
+    # workload, a few steps, outside the timed region
+    fp32 = None
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.train_only:
+        del trainer, model
+        torch.cuda.empty_cache()
+        m32 = flair_amd.create_model("unet", "resnet34", encoder_weights=None, in_channels=5, classes=args.classes,
+                                     compute_dtype="f32").to(dev).train()
+        t32 = flair_amd.SegTrainer(m32, lr=1e-3)
+        for _ in range(2):
+            t32.train_step(img, lab)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n32 = 4
+        for _ in range(n32):
+            t32.train_step(img, lab)
+        torch.cuda.synchronize()
+        d32 = (time.perf_counter() - t2) / n32
+        v32 = args.batch / d32
+        fp32 = {"fp32_parity_tiles_per_s": round(v32, 2), "fp32_parity_ms_per_step": round(1e3 * d32, 3),
+                "fp32_parity_frac_of_157TF": round(v32 * TRAIN_GFLOP_PER_TILE / 1e3 / PEAK["f32"], 4)}
+        del t32, m32
+        torch.cuda.empty_cache()
 
     if world > 1:
         t = torch.tensor([dt, dti], dtype=torch.float64, device=dev)
@@ -254,23 +345,7 @@ def main():
         }
         if prof:
             tot = sum(r["ms"] for r in prof)
-            d = prof[0]
-            per_launch_s = d["ms"] / 1e3 / d["launches"]
-            if d["flops"] > 0:
-                ach = d["flops"] / d["launches"] / per_launch_s / 1e12
-                res["roofline"] = {"kernel": d["kernel"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.dtype],
-                                   "unit": "TFLOP/s", "frac": round(ach / PEAK[args.dtype], 4),
-                                   "traffic": pmc_traffic(d["kernel"]) if args.dtype == "bf16" and args.batch == 32 and args.size == 512 else None,
-                                   "traffic_unit": "HBM bytes/launch (PMC, profiles/r1_pmc_traffic.json)",
-                                   "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
-                                   "launches_per_step": d["launches"], "avg_launch_us": round(per_launch_s * 1e6, 2),
-                                   "share_of_kernel_time": round(d["ms"] / tot, 3)}
-            else:
-                ach = d["bytes"] / d["launches"] / per_launch_s / 1e9
-                res["roofline"] = {"kernel": d["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                   "launches_per_step": d["launches"], "avg_launch_us": round(per_launch_s * 1e6, 2),
-                                   "share_of_kernel_time": round(d["ms"] / tot, 3)}
+            res["roofline"] = roofline_obj(prof, args, full_workload)
             # sum over BOTH streams (weight gradients run beside the BN / data-gradient chain): exceeds ms_per_step
             res["kernel_time_ms_per_step"] = round(tot, 3)
             res["kernel_time_note"] = "sum of per-kernel HIP-event times over two overlapping streams"
@@ -279,6 +354,15 @@ def main():
                     tf = r["flops"] / (r["ms"] / 1e3) / 1e12 if r["ms"] > 0 else 0
                     gb = r["bytes"] / (r["ms"] / 1e3) / 1e9 if r["ms"] > 0 else 0
                     print(f"{r['kernel']:28s} {r['ms']:9.3f} ms {r['launches']:5d} launches {tf:8.1f} TFLOP/s {gb:9.1f} GB/s(alg)", file=sys.stderr)
+        if prof_alone:
+            ra = roofline_obj(prof_alone, args, full_workload, kernel=res.get("roofline", {}).get("kernel"))
+            ra["note"] = ("the same kernel in one extra step with the weight-gradient side stream off (FLAIR_WGRAD_STREAM=0): "
+                          "no other kernel shares the CUs; `roofline` above is the timed region as it runs")
+            res["roofline_alone"] = ra
+        if prof_inf:
+            res["inference_roofline"] = roofline_obj(prof_inf, args, full_workload)
+        if fp32:
+            res.update(fp32)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(2, args.size, args.classes, iters=24)
         print(json.dumps(res), flush=True)

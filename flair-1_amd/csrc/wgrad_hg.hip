@@ -277,22 +277,75 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
     }
     if (kg == 1) return;
   }
-  // every (remaining) wave owns a disjoint block of the gradient: write the slab directly
-  const int Cin = a.C0 + a.C1;
-  float* __restrict__ part = a.partial + (long)blockIdx.x * a.Cout * a.Kg;
-  const int lr = lane & 15, lq = lane >> 4;
+  // Every (remaining) wave owns a disjoint block of the gradient.  The slab is stored in the order the accumulators sit
+  // in registers — one 16-byte store per lane and accumulator tile, 1 KiB contiguous per wave-instruction (the
+  // [cout][9*Cin] image of round 1 cost four 4-byte stores per tile in 64-byte segments: the tail was store-issue bound,
+  // ~20 us of a ~100 us kernel).  wgrad_big_reduce_kernel undoes the permutation while it sums the slabs.
+  //   slab of workgroup (x, y, z) at ((x * gridDim.y + y) * gridDim.z + z) * (CO * 9 * CK) floats,
+  //   element [wave-slot][co][ci][tap][lane][e]
+  constexpr int WSLOTS = Cfg::WK * 2;   // waves that hold a block (KG == 2: the upper tile-row half only)
+  float* __restrict__ part = a.partial + (((long)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (long)(CO * 9 * CK);
+  const int wslot = wc * Cfg::WK + wk;
+  float4* __restrict__ dst = reinterpret_cast<float4*>(part) + (long)wslot * (COT * CIT * 9 * 64) + lane;
+  (void)WSLOTS;
 #pragma unroll
   for (int co = 0; co < COT; ++co)
 #pragma unroll
     for (int ci = 0; ci < CIT; ++ci)
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp)
+        dst[((co * CIT + ci) * 9 + tp) * 64] = make_float4(acc[co][ci][tp][0], acc[co][ci][tp][1], acc[co][ci][tp][2], acc[co][ci][tp][3]);
+}
+
+// Ordered sum of the nsplit slabs of every (input-channel block y, output-channel block z) + the permutation back to
+// PyTorch OIHW.  One thread per 16-byte slab element (four consecutive output channels of one (tap, cin)): coalesced
+// 1 KiB slab reads, four independent partial sums in flight, fixed order -> bit-reproducible.
+template <int CH, int KG>
+__global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit,
+                                                               int ny, int nz, int Cin, int Cin_real, int accumulate) {
+  constexpr int CK = 8 * CH, CO = 16 * CH / KG, WK = 4 / KG, COT = CO / WK / 16, CIT = CK / 2 / 16;
+  constexpr int BLK4 = CO * 9 * CK / 4;   // float4 elements per slab
+  const long total = (long)ny * nz * BLK4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int el = (int)(idx % BLK4);
+    const int yz = (int)(idx / BLK4);
+    const int z = yz % nz, y = yz / nz;
+    const float4* p = reinterpret_cast<const float4*>(part) + ((long)y * nz + z) * BLK4 + el;
+    const long xs = (long)ny * nz * BLK4;   // stride between the slabs of consecutive pixel splits
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    int x = 0;
+    for (; x + 3 < nsplit; x += 4) {
+      const float4 v0 = p[(long)x * xs], v1 = p[(long)(x + 1) * xs], v2 = p[(long)(x + 2) * xs], v3 = p[(long)(x + 3) * xs];
+      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+      s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+      s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+      s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+    }
+    for (; x < nsplit; ++x) {
+      const float4 v0 = p[(long)x * xs];
+      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+    }
+    const float r[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                        (s0.w + s1.w) + (s2.w + s3.w)};
+    // el = ((wslot * COT + co) * CIT + ci) * 9 * 64 + tap * 64 + lane
+    const int lane = el & 63;
+    int q = el >> 6;
+    const int tp = q % 9; q /= 9;
+    const int ci = q % CIT; q /= CIT;
+    const int co = q % COT; q /= COT;
+    const int wk = q % WK, wc = q / WK;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int c = y * CK + (wc * CIT + ci) * 16 + lr;
+    if (c < Cin_real) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = kbase + (wk * COT + co) * 16 + lq * 4 + e;
-          const int c = cbase + (wc * CIT + ci) * 16 + lr;
-          part[(long)k * a.Kg + tp * Cin + c] = acc[co][ci][tp][e];
-        }
+      for (int e = 0; e < 4; ++e) {
+        const int k = z * CO + (wk * COT + co) * 16 + lq * 4 + e;
+        float* d = dw + ((long)k * Cin_real + c) * 9 + tp;
+        *d = accumulate ? (*d + r[e]) : r[e];
+      }
+    }
+  }
+  (void)Cin;
 }
 
 }  // namespace
@@ -364,7 +417,22 @@ int launch_wgrad_big(int dtype, const WgradArgs& a, hipStream_t s) {
   if (dtype == DT_F32) rc = kg == 1 ? launch_big_t<float, 1>(h, nsplit, Cin, s) : launch_big_t<float, 2>(h, nsplit, Cin, s);
   else rc = kg == 1 ? launch_big_t<bf16_t, 1>(h, nsplit, Cin, s) : launch_big_t<bf16_t, 2>(h, nsplit, Cin, s);
   if (rc) return rc;
-  launch_wgrad_reduce(a.partial, a.dw, nsplit, a.Cout, a.Cout, 9 * Cin, Cin, a.Cin_real, 3, 3, a.accumulate, s);
+  {
+    const int ch = dtype == DT_F32 ? 4 : 8;
+    const int ck = 8 * ch, co = 16 * ch / kg;
+    const int ny = Cin / ck, nz = a.Cout / co;
+    const long total4 = (long)a.Cout * 9 * Cin / 4;
+    int blocks = cdiv(total4, 256);
+    if (blocks > 4096) blocks = 4096;
+    ProfScope ps("wgrad_reduce", 0.0, ((double)nsplit + 1.0) * a.Cout * 9.0 * Cin * 4.0, s);
+    if (dtype == DT_F32) {
+      if (kg == 1) hipLaunchKernelGGL((wgrad_big_reduce_kernel<4, 1>), dim3(blocks), dim3(256), 0, s, a.partial, a.dw, nsplit, ny, nz, Cin, a.Cin_real, a.accumulate);
+      else hipLaunchKernelGGL((wgrad_big_reduce_kernel<4, 2>), dim3(blocks), dim3(256), 0, s, a.partial, a.dw, nsplit, ny, nz, Cin, a.Cin_real, a.accumulate);
+    } else {
+      if (kg == 1) hipLaunchKernelGGL((wgrad_big_reduce_kernel<8, 1>), dim3(blocks), dim3(256), 0, s, a.partial, a.dw, nsplit, ny, nz, Cin, a.Cin_real, a.accumulate);
+      else hipLaunchKernelGGL((wgrad_big_reduce_kernel<8, 2>), dim3(blocks), dim3(256), 0, s, a.partial, a.dw, nsplit, ny, nz, Cin, a.Cin_real, a.accumulate);
+    }
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

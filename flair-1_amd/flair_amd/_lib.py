@@ -70,6 +70,8 @@ PROTOTYPES = {
     "flair_profile_stop": (i32, []),
     "flair_profile_kernel": (i32, [i32, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
+    "flair_metadata_mlp_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "flair_metadata_mlp_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "flair_tune_set": (i32, [C.c_char_p, i32]),
     "flair_debug_buffer": (i32, [vp]),
 }

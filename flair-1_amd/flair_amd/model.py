@@ -31,8 +31,48 @@ class _AddRowVec(torch.autograd.Function):
         return g, g.sum(dim=(1, 3))
 
 
+def _ptr3(ts):
+    import ctypes as C
+    return (C.c_void_p * 3)(*[None if t is None else L.ptr(t) for t in ts])
+
+
+class _MlpFn(torch.autograd.Function):
+    """The three Linear + Dropout + ReLU layers as ONE HIP kernel each way (flair_metadata_mlp_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, masks):
+        x = x.detach().float().contiguous()
+        B = x.shape[0]
+        ws = [w.detach().float().contiguous() for w in (w1, w2, w3)]
+        bs = [b.detach().float().contiguous() for b in (b1, b2, b3)]
+        h1 = torch.empty(B, 64, dtype=torch.float32, device=x.device)
+        h2 = torch.empty(B, 32, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, 16, dtype=torch.float32, device=x.device)
+        L.check(L.lib().flair_metadata_mlp_forward(L.ptr(x), _ptr3(ws), _ptr3(bs), None if masks is None else _ptr3(masks),
+                                                   L.ptr(h1), L.ptr(h2), L.ptr(out), B, L.stream()), "metadata_mlp_forward")
+        ctx.save_for_backward(x, h1, h2, out, *ws)
+        ctx.masks = masks
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, h1, h2, out, w1, w2, w3 = ctx.saved_tensors
+        B = x.shape[0]
+        dw = [torch.empty_like(w) for w in (w1, w2, w3)]
+        db = [torch.empty(n, dtype=torch.float32, device=x.device) for n in (64, 32, 16)]
+        scratch = torch.empty(B * 112, dtype=torch.float32, device=x.device)
+        L.check(L.lib().flair_metadata_mlp_backward(L.ptr(x), L.ptr(h1), L.ptr(h2), L.ptr(out), _ptr3([w1, w2, w3]),
+                                                    None if ctx.masks is None else _ptr3(ctx.masks),
+                                                    L.ptr(g.detach().float().contiguous()), B, _ptr3(dw), _ptr3(db),
+                                                    L.ptr(scratch), L.stream()), "metadata_mlp_backward")
+        return None, dw[0], db[0], dw[1], db[1], dw[2], db[2], None
+
+
 class MetadataMLP(nn.Module):
-    """Light MLP to encode metadata (model.py:74-96): 45 -> 64 -> 32 -> 16, Dropout(0.4) + ReLU each."""
+    """Light MLP to encode metadata (model.py:74-96): 45 -> 64 -> 32 -> 16, Dropout(0.4) + ReLU each.  Same module tree
+    and state_dict keys (enc_mlp.0 / .3 / .6) as the reference; on a HIP device the forward and backward are one kernel
+    each (csrc/metadata_mlp.hip), with the dropout masks drawn here from torch's generator in training mode.  Host
+    tensors (the CPU-side unit tests of the mirror) take the plain nn.Sequential."""
 
     def __init__(self):
         super().__init__()
@@ -42,8 +82,21 @@ class MetadataMLP(nn.Module):
             nn.Linear(32, 16), nn.Dropout(0.4), nn.ReLU(),
         )
 
-    def forward(self, x):
-        return self.enc_mlp(x)
+    def dropout_masks(self, B, device):
+        """Bernoulli(keep = 0.6) / 0.6 per layer, as nn.Dropout(0.4) applies them; None in eval mode."""
+        if not self.training:
+            return None
+        return [torch.bernoulli(torch.full((B, n), 0.6, device=device)) / 0.6 for n in (64, 32, 16)]
+
+    def forward(self, x, masks="auto"):
+        if not x.is_cuda:
+            return self.enc_mlp(x)
+        if x.dim() != 2 or x.shape[1] != 45 or x.shape[0] > 256:
+            raise ValueError("MetadataMLP expects (B <= 256, 45) metadata vectors")
+        if masks == "auto":
+            masks = self.dropout_masks(x.shape[0], x.device)
+        l1, l2, l3 = self.enc_mlp[0], self.enc_mlp[3], self.enc_mlp[6]
+        return _MlpFn.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, masks)
 
 
 class FLAIR_ModelFactory(nn.Module):

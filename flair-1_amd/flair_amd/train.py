@@ -84,7 +84,10 @@ class SegTrainer:
         self._preds = None
         self._ce_ws = None
         if self.exchange:
-            self.comm_stream = torch.cuda.Stream(device=dev)
+            # HIGH priority: its own hardware queues (HIP multiplexes streams over a few queues per priority level; a
+            # normal-priority stream can land on the caller's queue and serialise the collectives behind the backward
+            # kernels they are meant to overlap), and a bucket's all-reduce is dispatched as soon as its stage event fires
+            self.comm_stream = torch.cuda.Stream(device=dev, priority=-1)
             self.events = [torch.cuda.Event() for _ in range(7)]
             for e in self.events:
                 e.record()  # materialise the hipEvent_t handles

@@ -187,6 +187,19 @@ int flair_nchw_to_nhwc(int dtype, const float* x_nchw, void* y_nhwc, int N, int 
 int flair_nhwc_to_nchw(int dtype, const void* x_nhwc, float* y_nchw, int N, int C, int H, int W, int Cpad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MetadataMLP (replaces /root/reference/src/flair/model.py:74-96, called at model.py:58): Linear(45,64) -> Dropout(0.4) ->
+ * ReLU -> Linear(64,32) -> Dropout -> ReLU -> Linear(32,16) -> Dropout -> ReLU.  x [B][45] fp32; w[i] / b[i] the three
+ * nn.Linear weights ([out][in]) and biases; mask[i] optional [B][64|32|16] dropout masks ALREADY scaled by 1/(1-p)
+ * (NULL array or NULL entries: eval mode); h1 [B][64], h2 [B][32] receive the hidden activations (needed by backward,
+ * may be NULL); out [B][16].  backward: dout [B][16] -> dw[i] / db[i] (overwritten); scratch >= B*112 floats; B <= 256.
+ * The metadata vector is a model input: no gradient w.r.t. x is produced (the reference never asks for one). */
+int flair_metadata_mlp_forward(const float* x, const float* const w[3], const float* const b[3], const float* const mask[3],
+                               float* h1, float* h2, float* out, int B, void* stream);
+int flair_metadata_mlp_backward(const float* x, const float* h1, const float* h2, const float* out, const float* const w[3],
+                                const float* const mask[3], const float* dout, int B, float* const dw[3], float* const db[3],
+                                float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement aid (bench.py "roofline"): while enabled every kernel launch of the library is bracketed by
  * HIP events on its launch stream.  stop() synchronises the device and returns the number of distinct
  * kernels; kernel(i) gives total time, launch count and the ALGORITHMIC flops / bytes of those launches. */

@@ -557,3 +557,38 @@ def test_checkpoint_files_drive_the_hip_model(dev, tmp_path):
     assert lg13.shape == (2, 13, 96, 64) and float(lg13.abs().max()) == 0.0
     k = "encoder.layer2.1.conv2.weight"
     assert torch.equal(seg13.state_dict()[k].cpu(), ref.state_dict()[k])
+
+
+def test_metadata_mlp_kernel_matches_reference_module(dev):
+    """MetadataMLP (model.py:74-96) as one HIP kernel each way: eval mode against the plain nn.Sequential of the
+    reference, training mode with SUPPLIED dropout masks against the same arithmetic in torch (outputs 1e-6, parameter
+    gradients 1e-5 relative); state_dict keys are the reference's."""
+    import flair_amd
+    torch.manual_seed(5)
+    mlp = flair_amd.MetadataMLP()
+    assert list(mlp.state_dict()) == ["enc_mlp.0.weight", "enc_mlp.0.bias", "enc_mlp.3.weight", "enc_mlp.3.bias",
+                                      "enc_mlp.6.weight", "enc_mlp.6.bias"]
+    x = torch.randn(7, 45)
+    mlp.eval()
+    with torch.no_grad():
+        want = mlp(x)                       # host tensors: the reference's module tree
+    hip = flair_amd.MetadataMLP()
+    hip.load_state_dict(mlp.state_dict())
+    hip = hip.to(dev).eval()
+    with torch.no_grad():
+        got = hip(x.to(dev)).cpu()
+    assert float((got - want).abs().max()) < 1e-6
+    # training mode, masks supplied (Dropout sits BEFORE the ReLU in the reference: mask * pre-activation)
+    hip.train()
+    masks = [torch.bernoulli(torch.full((7, n), 0.6, generator=None)) / 0.6 for n in (64, 32, 16)]
+    out = hip(x.to(dev), masks=[m.to(dev) for m in masks])
+    w = torch.randn(7, 16)
+    (out * w.to(dev)).sum().backward()
+    ref = [p.detach().clone().requires_grad_(True) for p in mlp.parameters()]
+    h = x
+    for i in range(3):
+        h = torch.relu((h @ ref[2 * i].t() + ref[2 * i + 1]) * masks[i])
+    assert float((out.detach().cpu() - h).abs().max()) < 1e-6
+    (h * w).sum().backward()
+    for p, r in zip(hip.parameters(), ref):
+        assert float((p.grad.cpu() - r.grad).abs().max()) <= 1e-5 * max(1.0, float(r.grad.abs().max()))
