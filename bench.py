@@ -274,7 +274,7 @@ def main():
 
     # the dominant kernel alone: one more step with the weight gradients on the caller's stream (outside the timed region)
     prof_alone = []
-    if rank == 0 and not args.no_alone:
+    if world == 1 and not args.no_alone:   # (single rank only: a lone extra step would wait in the all-reduce for ever)
         L.lib().flair_tune_set(b"FLAIR_WGRAD_STREAM", 0)
         trainer.train_step(img, lab)
         L.check(L.lib().flair_profile_start(4096))

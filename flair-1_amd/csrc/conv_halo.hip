@@ -90,18 +90,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  for (int cbase = 0; cbase < Cin; cbase += CK) {
-    if (cbase) __syncthreads();  // previous chunk fully consumed
-    // ---- stage the halo chunk and the weight chunk: all loads first, then all LDS writes
+  // The next chunk's halo and weights ride in registers while the current chunk is multiplied (multi-chunk layers:
+  // decoder block 3's 128 -> 32 convolution has four; round 1 loaded, waited, staged and only then multiplied).
+  u32x4 hreg[Cfg::HITEMS], wreg[Cfg::WITEMS];
+  unsigned hbits = 0;
+  float lsc[CH], lsh[CH];   // lazy BN + ReLU of the producing unit: a thread always stages the same chunk column (256 % CPP == 0)
+  auto load_chunk = [&](int cbase) {
     const bool use0 = cbase < a.C0;
     const T* __restrict__ base = use0 ? src0 : src1;
     const int Hs = use0 ? Hs0 : H, Ws = use0 ? Ws0 : W, Cs = use0 ? a.C0 : a.C1;
     const int sh = (use0 && a.up0) ? 1 : 0;
     const int coff = use0 ? cbase : cbase - a.C0;
-    u32x4 hreg[Cfg::HITEMS], wreg[Cfg::WITEMS];
-    unsigned hmask[Cfg::HITEMS];
-    // lazy BN + ReLU of the producing unit: a thread always stages the same chunk column (256 % CPP == 0)
-    float lsc[CH], lsh[CH];
     if (LZ && a.in_scale) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
@@ -109,6 +108,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
         lsh[e] = a.in_shift[cbase + (t % CPP) * CH + e];
       }
     }
+    unsigned hb2 = 0;
 #pragma unroll
     for (int k = 0; k < Cfg::HITEMS; ++k) {
       const int it = t + 256 * k;
@@ -118,8 +118,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
       const bool ok = (it < HPIX * CPP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
       const unsigned off = ok ? (unsigned)(((n * Hs + (iy >> sh)) * Ws + (ix >> sh)) * Cs + coff + ch * CH) : 0u;
       hreg[k] = *reinterpret_cast<const u32x4*>(base + off);
-      hmask[k] = ok ? 0xffffffffu : 0u;
+      hb2 |= (ok ? 1u : 0u) << k;
     }
+    hbits = hb2;
 #pragma unroll
     for (int k = 0; k < Cfg::WITEMS; ++k) {
       const int it = t + 256 * k;
@@ -128,13 +129,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
       const int tap = rem / CPP, ch = rem - tap * CPP;
       wreg[k] = *reinterpret_cast<const u32x4*>(wp + (long)(n0 + row) * a.Kpad + tap * Cin + cbase + ch * CH);
     }
+  };
+  load_chunk(0);
+  for (int cbase = 0; cbase < Cin; cbase += CK) {
+    if (cbase) __syncthreads();  // previous chunk fully consumed
 #pragma unroll
     for (int k = 0; k < Cfg::HITEMS; ++k) {
       const int it = t + 256 * k;
       if (it < HPIX * CPP) {
         const int hp = it / CPP, ch = it - hp * CPP;
         const u32x4 hv = (LZ && a.in_scale) ? chunk_bn_relu<T>(hreg[k], lsc, lsh) : hreg[k];
-        *reinterpret_cast<u32x4*>(halo + hp * Cfg::PSTRIDE + ch * 16) = hv & hmask[k];
+        *reinterpret_cast<u32x4*>(halo + hp * Cfg::PSTRIDE + ch * 16) = hv & (0u - ((hbits >> k) & 1u));
       }
     }
 #pragma unroll
@@ -144,6 +149,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
         const int row = it / (9 * CPP), rem = it - row * (9 * CPP);
         *reinterpret_cast<u32x4*>(wl + row * Cfg::WROW + rem * 16) = wreg[k];
       }
+    }
+    if (cbase + CK < Cin) {
+      load_chunk(cbase + CK);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMA phase
     }
     __syncthreads();
     // ---- 9 taps x CK channels from LDS

@@ -128,23 +128,28 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
     }
   }
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int n = tile / (tiles_x * tiles_y);
-    const int trem = tile - n * tiles_x * tiles_y;
+  // The next tile's X halo and dY tile ride in registers while the current tile is multiplied (round 1 issued the loads
+  // of a tile, waited for them and only then computed: with ~3 workgroups per CU the HBM latency of every tile was
+  // exposed — 330 us for 300 MB, a fifth of the HBM rate).
+  u32x4 xr[Cfg::XITEMS], dr[Cfg::DITEMS];
+  unsigned xbits = 0, dbits = 0;
+  auto load_tile = [&](int tile) {
+    const bool tok = tile < a.ntiles;
+    const int tl = tok ? tile : 0;
+    const int n = tl / (tiles_x * tiles_y);
+    const int trem = tl - n * tiles_x * tiles_y;
     const int y0 = (trem / tiles_x) * TH, x0p = (trem % tiles_x) * TW;
-    // ---- all loads of the tile first (X halo chunk + dY tile), then the LDS writes
-    u32x4 xr[Cfg::XITEMS], dr[Cfg::DITEMS];
-    unsigned xm[Cfg::XITEMS], dm[Cfg::DITEMS];
+    unsigned xb2 = 0, db2 = 0;
 #pragma unroll
     for (int k = 0; k < Cfg::XITEMS; ++k) {
       const int it = t + 256 * k;
       const int hp = it / CPP, ch = it - hp * CPP;
       const int hy = hp / HW_, hx = hp - hy * HW_;
       const int iy = y0 - 1 + hy, ix = x0p - 1 + hx;
-      const bool ok = (it < HPIX * CPP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+      const bool ok = tok && (it < HPIX * CPP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
       const unsigned off = ok ? (unsigned)(((n * Hs + (iy >> sh)) * Ws + (ix >> sh)) * Cs + coff + ch * CH) : 0u;
       xr[k] = *reinterpret_cast<const u32x4*>(xb + off);
-      xm[k] = ok ? 0xffffffffu : 0u;
+      xb2 |= (ok ? 1u : 0u) << k;
     }
 #pragma unroll
     for (int k = 0; k < Cfg::DITEMS; ++k) {
@@ -152,11 +157,15 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
       const int px = it / DPP, ch = it - px * DPP;
       const int py = px / TW, pxx = px - py * TW;
       const int col = kbase + ch * CH;
-      const bool ok = (it < TH * TW * DPP) && col < a.dy_ld;
+      const bool ok = tok && (it < TH * TW * DPP) && col < a.dy_ld;
       const unsigned off = ok ? (unsigned)(((n * H + y0 + py) * W + x0p + pxx) * a.dy_ld + col) : 0u;
       dr[k] = *reinterpret_cast<const u32x4*>(dy + off);
-      dm[k] = ok ? 0xffffffffu : 0u;
+      db2 |= (ok ? 1u : 0u) << k;
     }
+    xbits = xb2; dbits = db2;
+  };
+  load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();  // the previous tile's fragment reads are done
 #pragma unroll
     for (int k = 0; k < Cfg::XITEMS; ++k) {
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
       if (it < HPIX * CPP) {
         const int hp = it / CPP, ch = it - hp * CPP;
         const u32x4 xv = (LZ && a.in_scale) ? chunk_bn_relu<T>(xr[k], lsc, lsh) : xr[k];
-        *reinterpret_cast<u32x4*>(xh + hp * Cfg::XSTRIDE + ch * 16) = xv & xm[k];
+        *reinterpret_cast<u32x4*>(xh + hp * Cfg::XSTRIDE + ch * 16) = xv & (0u - ((xbits >> k) & 1u));
       }
     }
 #pragma unroll
@@ -172,9 +181,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
       const int it = t + 256 * k;
       if (it < TH * TW * DPP) {
         const int px = it / DPP, ch = it - px * DPP;
-        *reinterpret_cast<u32x4*>(dyt + px * Cfg::DSTRIDE + ch * 16) = dr[k] & dm[k];
+        *reinterpret_cast<u32x4*>(dyt + px * Cfg::DSTRIDE + ch * 16) = dr[k] & (0u - ((dbits >> k) & 1u));
       }
     }
+    load_tile(tile + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMA phase (hipcc would sink it to its use)
     __syncthreads();
     // ---- this wave's tile rows (K = ROWS x 32 pixels) of its 16x16 gradient block, all nine taps
 #pragma unroll

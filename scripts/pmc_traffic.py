@@ -16,10 +16,13 @@ import sys
 
 # rocprofv3 kernel name -> the name bench.py's live event table uses for the same launches
 ALIASES = [
-    (r"conv3x3_hg_kernel<unsigned short, \d+, \d+, 128", "conv3x3_hg_bf16_n128"),
-    (r"conv3x3_hg_kernel<unsigned short, \d+, \d+, 64", "conv3x3_hg_bf16_n64"),
-    (r"conv3x3_hg_kernel<float, \d+, \d+, 128", "conv3x3_hg_f32_n128"),
-    (r"conv3x3_hg_kernel<float, \d+, \d+, 64", "conv3x3_hg_f32_n64"),
+    (r"conv3x3_hgd?_kernel<unsigned short, \d+, \d+, 128", "conv3x3_hg_bf16_n128"),
+    (r"conv3x3_hgd?_kernel<unsigned short, \d+, \d+, 64", "conv3x3_hg_bf16_n64"),
+    (r"conv3x3_hgd?_kernel<float, \d+, \d+, 128", "conv3x3_hg_f32_n128"),
+    (r"conv3x3_hgd?_kernel<float, \d+, \d+, 64", "conv3x3_hg_f32_n64"),
+    (r"wgrad3x3_big_kernel<unsigned short, 1", "wgrad3x3_big_bf16"),
+    (r"wgrad3x3_big_kernel<unsigned short, 2", "wgrad3x3_big_bf16_co64"),
+    (r"wgrad_big_reduce_kernel|wgrad_reduce_kernel", "wgrad_reduce"),
 ]
 
 
@@ -56,7 +59,13 @@ def main():
         wr = vw / nw * 1024.0
         res[k] = {"launches_sampled": nf, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                          "hbm_bytes_per_launch": round(rd + wr)}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 "
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        commit = None
+    commit = (sys.argv[4] if len(sys.argv) > 4 else commit)
+    json.dump({"commit": commit, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 "
                          "--train-only; KiB -> bytes, FETCH_SIZE doubled (gfx950)", "kernels": res}, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:12]:
         print(f"{k[:60]:60s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch  x{v['launches_sampled']}")

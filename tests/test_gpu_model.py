@@ -580,7 +580,7 @@ def test_metadata_mlp_kernel_matches_reference_module(dev):
     assert float((got - want).abs().max()) < 1e-6
     # training mode, masks supplied (Dropout sits BEFORE the ReLU in the reference: mask * pre-activation)
     hip.train()
-    masks = [torch.bernoulli(torch.full((7, n), 0.6, generator=None)) / 0.6 for n in (64, 32, 16)]
+    masks = [torch.bernoulli(torch.full((7, n), 0.6)) / 0.6 for n in (64, 32, 16)]
     out = hip(x.to(dev), masks=[m.to(dev) for m in masks])
     w = torch.randn(7, 16)
     (out * w.to(dev)).sum().backward()
