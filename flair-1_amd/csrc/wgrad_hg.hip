@@ -298,54 +298,80 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
 }
 
 // Ordered sum of the nsplit slabs of every (input-channel block y, output-channel block z) + the permutation back to
-// PyTorch OIHW.  One thread per 16-byte slab element (four consecutive output channels of one (tap, cin)): coalesced
-// 1 KiB slab reads, four independent partial sums in flight, fixed order -> bit-reproducible.
-template <int CH, int KG>
+// PyTorch OIHW.  A workgroup handles 256 / G slab elements (16 bytes = four consecutive output channels of one
+// (tap, cin)); its G thread groups each sum the slabs x = g, g + G, ... with two partial sums in flight, then group 0 adds
+// the G partials in a fixed order: bit-reproducible.  G = 16 for the many-slab layers (64 -> 64 at 128^2: 256 slabs of a
+// 147 KB gradient — with one thread per element that launch had 36 workgroups and ran at 0.5 TB/s), G = 4 otherwise.
+template <int CH, int KG, int G>
 __global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit,
-                                                               int ny, int nz, int Cin, int Cin_real, int accumulate) {
+                                                               int ny, int nz, int Cin_real, int accumulate) {
   constexpr int CK = 8 * CH, CO = 16 * CH / KG, WK = 4 / KG, COT = CO / WK / 16, CIT = CK / 2 / 16;
   constexpr int BLK4 = CO * 9 * CK / 4;   // float4 elements per slab
+  constexpr int E = 256 / G;
+  __shared__ float4 sh[G][E];
   const long total = (long)ny * nz * BLK4;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int el = (int)(idx % BLK4);
-    const int yz = (int)(idx / BLK4);
-    const int z = yz % nz, y = yz / nz;
-    const float4* p = reinterpret_cast<const float4*>(part) + ((long)y * nz + z) * BLK4 + el;
-    const long xs = (long)ny * nz * BLK4;   // stride between the slabs of consecutive pixel splits
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-    int x = 0;
-    for (; x + 3 < nsplit; x += 4) {
-      const float4 v0 = p[(long)x * xs], v1 = p[(long)(x + 1) * xs], v2 = p[(long)(x + 2) * xs], v3 = p[(long)(x + 3) * xs];
-      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
-      s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
-      s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
-      s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
-    }
-    for (; x < nsplit; ++x) {
-      const float4 v0 = p[(long)x * xs];
-      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
-    }
-    const float r[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
-                        (s0.w + s1.w) + (s2.w + s3.w)};
-    // el = ((wslot * COT + co) * CIT + ci) * 9 * 64 + tap * 64 + lane
-    const int lane = el & 63;
-    int q = el >> 6;
-    const int tp = q % 9; q /= 9;
-    const int ci = q % CIT; q /= CIT;
-    const int co = q % COT; q /= COT;
-    const int wk = q % WK, wc = q / WK;
-    const int lr = lane & 15, lq = lane >> 4;
-    const int c = y * CK + (wc * CIT + ci) * 16 + lr;
-    if (c < Cin_real) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = z * CO + (wk * COT + co) * 16 + lq * 4 + e;
-        float* d = dw + ((long)k * Cin_real + c) * 9 + tp;
-        *d = accumulate ? (*d + r[e]) : r[e];
+  const int e = threadIdx.x % E, g = threadIdx.x / E;
+  const long xs = (long)ny * nz * BLK4;   // stride between the slabs of consecutive pixel splits
+  for (long base = (long)blockIdx.x * E; base < total; base += (long)gridDim.x * E) {
+    const long idx = base + e;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (idx < total) {
+      const float4* p = reinterpret_cast<const float4*>(part) + idx;
+      int x = g;
+      for (; x + G < nsplit; x += 2 * G) {
+        const float4 v0 = p[(long)x * xs], v1 = p[(long)(x + G) * xs];
+        s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+        s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+      }
+      if (x < nsplit) {
+        const float4 v0 = p[(long)x * xs];
+        s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
       }
     }
+    sh[g][e] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (g == 0 && idx < total) {
+      float4 r4 = sh[0][e];
+#pragma unroll
+      for (int q = 1; q < G; ++q) { const float4 v = sh[q][e]; r4.x += v.x; r4.y += v.y; r4.z += v.z; r4.w += v.w; }
+      const float r[4] = {r4.x, r4.y, r4.z, r4.w};
+      const int el = (int)(idx % BLK4);
+      const int yz = (int)(idx / BLK4);
+      const int z = yz % nz, y = yz / nz;
+      // el = ((wslot * COT + co) * CIT + ci) * 9 * 64 + tap * 64 + lane
+      const int lane = el & 63;
+      int q = el >> 6;
+      const int tp = q % 9; q /= 9;
+      const int ci = q % CIT; q /= CIT;
+      const int co = q % COT; q /= COT;
+      const int wk = q % WK, wc = q / WK;
+      const int lr = lane & 15, lq = lane >> 4;
+      const int c = y * CK + (wc * CIT + ci) * 16 + lr;
+      if (c < Cin_real) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const int k = z * CO + (wk * COT + co) * 16 + lq * 4 + k4;
+          float* d = dw + ((long)k * Cin_real + c) * 9 + tp;
+          *d = accumulate ? (*d + r[k4]) : r[k4];
+        }
+      }
+    }
+    __syncthreads();
   }
-  (void)Cin;
+}
+
+template <int CH, int KG>
+static void launch_big_reduce(const float* part, float* dw, int nsplit, int ny, int nz, long total4, int Cin_real, int accumulate,
+                              hipStream_t s) {
+  if (nsplit >= 64) {
+    int blocks = cdiv(total4, 16);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((wgrad_big_reduce_kernel<CH, KG, 16>), dim3(blocks), dim3(256), 0, s, part, dw, nsplit, ny, nz, Cin_real, accumulate);
+  } else {
+    int blocks = cdiv(total4, 64);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((wgrad_big_reduce_kernel<CH, KG, 4>), dim3(blocks), dim3(256), 0, s, part, dw, nsplit, ny, nz, Cin_real, accumulate);
+  }
 }
 
 }  // namespace
@@ -422,15 +448,13 @@ int launch_wgrad_big(int dtype, const WgradArgs& a, hipStream_t s) {
     const int ck = 8 * ch, co = 16 * ch / kg;
     const int ny = Cin / ck, nz = a.Cout / co;
     const long total4 = (long)a.Cout * 9 * Cin / 4;
-    int blocks = cdiv(total4, 256);
-    if (blocks > 4096) blocks = 4096;
     ProfScope ps("wgrad_reduce", 0.0, ((double)nsplit + 1.0) * a.Cout * 9.0 * Cin * 4.0, s);
     if (dtype == DT_F32) {
-      if (kg == 1) hipLaunchKernelGGL((wgrad_big_reduce_kernel<4, 1>), dim3(blocks), dim3(256), 0, s, a.partial, a.dw, nsplit, ny, nz, Cin, a.Cin_real, a.accumulate);
-      else hipLaunchKernelGGL((wgrad_big_reduce_kernel<4, 2>), dim3(blocks), dim3(256), 0, s, a.partial, a.dw, nsplit, ny, nz, Cin, a.Cin_real, a.accumulate);
+      if (kg == 1) launch_big_reduce<4, 1>(a.partial, a.dw, nsplit, ny, nz, total4, a.Cin_real, a.accumulate, s);
+      else launch_big_reduce<4, 2>(a.partial, a.dw, nsplit, ny, nz, total4, a.Cin_real, a.accumulate, s);
     } else {
-      if (kg == 1) hipLaunchKernelGGL((wgrad_big_reduce_kernel<8, 1>), dim3(blocks), dim3(256), 0, s, a.partial, a.dw, nsplit, ny, nz, Cin, a.Cin_real, a.accumulate);
-      else hipLaunchKernelGGL((wgrad_big_reduce_kernel<8, 2>), dim3(blocks), dim3(256), 0, s, a.partial, a.dw, nsplit, ny, nz, Cin, a.Cin_real, a.accumulate);
+      if (kg == 1) launch_big_reduce<8, 1>(a.partial, a.dw, nsplit, ny, nz, total4, a.Cin_real, a.accumulate, s);
+      else launch_big_reduce<8, 2>(a.partial, a.dw, nsplit, ny, nz, total4, a.Cin_real, a.accumulate, s);
     }
   }
   hipError_t e = hipGetLastError();
