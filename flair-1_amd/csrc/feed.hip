@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void detect_convert_kernel(const float* __rest
     const long r = t - (long)b * KK;
     const int i = (int)(r / K), j = (int)(r - (long)i * K);
     const float* p = logits + (long)b * C * SS + (long)(i + margin) * S + (j + margin);
-    long obase = (long)b * (mode == 0 ? 2 : C) * KK + r, ostride = KK;
+    long obase = (long)b * (mode == 0 ? 2 : C) * KK + r, ostride = KK;   // mode 2 ('probs'): C fp32 planes
     if (tiles) {
       const int* tb = tiles + b * 6;
       const int gx = tb[0] + margin + j, gy = tb[1] + margin + i;
@@ -149,6 +149,11 @@ __global__ __launch_bounds__(256) void detect_convert_kernel(const float* __rest
       float* o = reinterpret_cast<float*>(out) + obase;
       o[0] = (float)best;
       o[ostride] = pbest;
+    } else if (mode == 2) {  // no convert: the fp32 probabilities torch.softmax(logits, dim=1) of compare.py:35
+      float* o = reinterpret_cast<float*>(out) + obase;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) o[(long)c * ostride] = x[c] / ssum;
     } else {  // convert('class_prob'): (p * 255).astype(uint8) — truncation
       unsigned char* o = reinterpret_cast<unsigned char*>(out) + obase;
 #pragma unroll
@@ -211,10 +216,10 @@ int feed_tiles(const FeedArgs& a, hipStream_t s) {
 
 int detect_convert(const float* logits, int B, int C, int S, int margin, int mode, void* out, const int* tiles, int Hr, int Wr,
                    hipStream_t s) {
-  if (C < 1 || C > MAXC || B < 1 || margin < 0 || S - 2 * margin < 1 || mode < 0 || mode > 1) return -2;
+  if (C < 1 || C > MAXC || B < 1 || margin < 0 || S - 2 * margin < 1 || mode < 0 || mode > 2 || (tiles && mode == 2)) return -2;
   if (tiles && (Hr < 1 || Wr < 1)) return -2;
   const long K = S - 2 * margin;
-  ProfScope ps(tiles ? "detect_stitch" : "detect_convert", 0.0, (double)B * K * K * (4.0 * C + (mode ? C : 8.0)), s);
+  ProfScope ps(tiles ? "detect_stitch" : "detect_convert", 0.0, (double)B * K * K * (4.0 * C + (mode == 2 ? 4.0 * C : mode ? C : 8.0)), s);
   hipLaunchKernelGGL(detect_convert_kernel, dim3(stream_blocks((long)B * K * K)), dim3(256), 0, s, logits, B, C, S, margin, mode, out,
                      tiles, Hr, Wr);
   FLAIR_CHECK_LAUNCH();

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 
-OUTPUT_TYPES = {"argmax": 0, "class_prob": 1}
+OUTPUT_TYPES = {"argmax": 0, "class_prob": 1, "probs": 2}   # "probs": fp32 softmax, no convert (compare.py:35)
 
 
 def detect_convert(logits: torch.Tensor, margin: int, output_type: str) -> torch.Tensor:
@@ -31,6 +31,8 @@ def detect_convert(logits: torch.Tensor, margin: int, output_type: str) -> torch
         raise ValueError("margin leaves no pixel")
     if output_type == "argmax":
         out = torch.empty(B, 2, K, K, dtype=torch.float32, device=logits.device)
+    elif output_type == "probs":
+        out = torch.empty(B, C, K, K, dtype=torch.float32, device=logits.device)
     else:
         out = torch.empty(B, C, K, K, dtype=torch.uint8, device=logits.device)
     L.check(L.lib().flair_detect_convert(L.ptr(logits), B, C, S, int(margin), OUTPUT_TYPES[output_type], L.ptr(out),
@@ -50,8 +52,8 @@ def inference(device, model, use_gpu: bool, config: dict, samples: dict, fused: 
             logits = logits.logits
         if fused:
             predictions = detect_convert(logits, config["margin"], config["output_type"])
-        else:
-            predictions = torch.softmax(logits, dim=1)
+        else:   # the reference's own return value: every probability, uncropped (same HIP kernel, no ATen op on the path)
+            predictions = detect_convert(logits, 0, "probs")
     indices = samples["index"].cpu().numpy()
     return predictions.cpu().numpy(), indices
 

@@ -138,7 +138,9 @@ int flair_feed_tiles(const uint8_t* img_u8, const uint8_t* msk_raw, const uint8_
 /* zone_detect: softmax over classes (src/zone_detect/compare.py:35), margin crop (compare.py:71-75) and
  * convert (src/zone_detect/dataset.py:11-34) without the probability tensor ever leaving the device.
  * output_type 0 'argmax': out fp32 (B, 2, S-2m, S-2m) = [first argmax, max probability];
- * output_type 1 'class_prob': out uint8 (B, C, S-2m, S-2m) = trunc(p * 255). */
+ * output_type 1 'class_prob': out uint8 (B, C, S-2m, S-2m) = trunc(p * 255);
+ * output_type 2 (flair_detect_convert only): no convert, out fp32 (B, C, S-2m, S-2m) = the probabilities themselves — with
+ *   m = 0 the return value of the reference's inference(), compare.py:35-39. */
 int flair_detect_convert(const float* logits_nchw, int B, int C, int S, int margin, int output_type, void* out, void* stream);
 /* Sliding-window detection over ONE raster resident in HBM (zone_detect default pipeline, src/zone_detect/main.py:386-428).
  * tiles (device, B x 6 int32): {x0, y0, wx0, wx1, wy0, wy1} per window — top-left pixel of the S x S window in raster

@@ -91,15 +91,27 @@ def _grad_errs(params, truth):
             for k, p in params}
 
 
-def _assert_as_good_as_cpu_fp32(e_hip, e_cpu):
+def _assert_as_good_as_cpu_fp32(e_hip, e_cpu, name="grad_vs_fp64", mult=(1.5, 2.0, 3.0)):
     """Gradients through 46 training-mode BatchNorms + ReLUs are ill-conditioned in fp32: a pre-activation
     within rounding of 0 flips its ReLU mask, so torch-CPU fp32 itself sits ~1e-2 (relative, max-norm) from
-    an fp64 run.  The bar for the HIP fp32 path is therefore 'as close to fp64 as the reference arithmetic'."""
+    an fp64 run.  The bar for the HIP fp32 path is therefore 'as close to fp64 as the reference arithmetic':
+    per-tensor relative max-norm errors against the fp64 oracle, HIP vs torch-CPU fp32, compared at the median, the
+    90th percentile and the maximum.  The measured ratios are logged (profiles/r2_parity.json); the multipliers are
+    those measurements plus margin for the run-to-run spread of WHICH pre-activations sit on a ReLU edge: whole-model
+    path measured 1.13x / 1.20x / 1.00x (bounds 1.5 / 2.0 / 3.0), split path — three more fp32 <-> NHWC round trips at the
+    sub-module boundaries — 1.57x / 2.06x / 1.15x (bounds 2.0 / 2.5 / 3.0)."""
+    from oracle import parity
     q = lambda d, f: sorted(d.values())[min(len(d) - 1, int(f * len(d)))]
-    assert q(e_hip, 0.5) <= 2.0 * q(e_cpu, 0.5) + 1e-4, (q(e_hip, 0.5), q(e_cpu, 0.5))
-    assert q(e_hip, 0.9) <= 2.5 * q(e_cpu, 0.9) + 1e-3, (q(e_hip, 0.9), q(e_cpu, 0.9))
+    entry = {"test": name, "tensors": len(e_hip),
+             "median_hip": q(e_hip, 0.5), "median_cpu_fp32": q(e_cpu, 0.5),
+             "p90_hip": q(e_hip, 0.9), "p90_cpu_fp32": q(e_cpu, 0.9),
+             "max_hip": max(e_hip.values()), "max_cpu_fp32": max(e_cpu.values())}
+    parity.record(entry)
+    entry["bounds"] = list(mult)
+    assert q(e_hip, 0.5) <= mult[0] * q(e_cpu, 0.5) + 1e-4, entry
+    assert q(e_hip, 0.9) <= mult[1] * q(e_cpu, 0.9) + 1e-3, entry
     # the maximum is a single-tensor outlier statistic (one flipped ReLU in a small layer): loose bound only
-    assert max(e_hip.values()) <= 5.0 * max(e_cpu.values()) + 2e-2, (max(e_hip.values()), max(e_cpu.values()))
+    assert max(e_hip.values()) <= mult[2] * max(e_cpu.values()) + 2e-2, entry
 
 
 def test_train_step_matches_oracle_elementwise_fp32(dev):
@@ -122,7 +134,7 @@ def test_train_step_matches_oracle_elementwise_fp32(dev):
     assert (lh.detach().cpu() - lr_.detach()).abs().max() < 1e-3
     assert (lh.detach().cpu().double() - l64.detach()).abs().max() < 1e-3
     p64 = dict(ref64.named_parameters())
-    _assert_as_good_as_cpu_fp32(_grad_errs(hip.named_parameters(), p64), _grad_errs(ref.named_parameters(), p64))
+    _assert_as_good_as_cpu_fp32(_grad_errs(hip.named_parameters(), p64), _grad_errs(ref.named_parameters(), p64), "grad_vs_fp64_unet_2x5x160x128")
     for k, b in hip.named_buffers():
         rb = dict(ref.named_buffers())[k]
         assert torch.allclose(b.cpu().float(), rb.float(), rtol=1e-4, atol=1e-5), k
@@ -231,9 +243,9 @@ def test_split_path_training_matches_fused(dev):
     f64[-1] = torch.add(f64[-1], enc64(mtd.double()).unsqueeze(1).unsqueeze(-1).repeat(1, 512, 1, 16))
     nn.functional.cross_entropy(ref64.segmentation_head(ref64.decoder(*f64)), lab).backward()
     p64 = dict(ref64.named_parameters())
-    _assert_as_good_as_cpu_fp32(_grad_errs(model.seg_model.named_parameters(), p64), _grad_errs(ref.named_parameters(), p64))
+    _assert_as_good_as_cpu_fp32(_grad_errs(model.seg_model.named_parameters(), p64), _grad_errs(ref.named_parameters(), p64), "grad_vs_fp64_split_path_unet", (2.0, 2.5, 3.0))
     e64 = dict(enc64.named_parameters())
-    _assert_as_good_as_cpu_fp32(_grad_errs(model.enc.named_parameters(), e64), _grad_errs(enc_cpu.named_parameters(), e64))
+    _assert_as_good_as_cpu_fp32(_grad_errs(model.enc.named_parameters(), e64), _grad_errs(enc_cpu.named_parameters(), e64), "grad_vs_fp64_split_path_mlp", (2.0, 2.5, 3.0))
 
 
 def test_bf16_throughput_mode_tracks_fp32(dev):
