@@ -23,6 +23,7 @@ const char* flair_strerror(int code) {
     case -4: return "fused upsample needs even extents";
     case -5: return "unsupported stride";
     case -6: return "requested fused epilogue / input transform is not available in the kernel this shape dispatches to";
+    case -7: return "diagnostic feature: rebuild with FLAIR_STAMPS=1";
     case -10: return "Wrong input shape: height and width must be divisible by 32";
     case -11: return "call order: backward / stage call without the matching forward on this workspace";
     case -12: return "gradient buffer already initialised";

@@ -452,11 +452,17 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
   const unsigned wbase = (unsigned)((wm * TM / MTX) * HW_ * 128);
 
   const int nsteps = 9 * nchunks;
+  // Phase stamps (scripts/stamp_hg.py) exist in the diagnostic build only (FLAIR_STAMPS=1 python flair-1_amd/build.py):
+  // in the shipped kernel no stamp executes (cdna_hip_programming.md §7, In-kernel stamps).
   auto stamp = [&](int i) {
-    if (a.dbg && t == 0) a.dbg[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
+#ifdef FLAIR_HG_STAMPS
+    if (a.dbg && t == 0) a.dbg[(size_t)blockIdx.x * 8 + i] = i == 5 || i == 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+#else
+    (void)i;
+#endif
   };
   stamp(0);
-  if (a.dbg && t == 0) a.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+  stamp(5);
   // Fragment reads and MFMAs are software-pipelined by hand in two register sets: set A holds half 0 of a tap (read
   // right after the barrier that publishes its weight tile), set B half 1 (read while half 0 multiplies).
   u32x4 afA[TM], bfA[TN], afB[TM], bfB[TN];
@@ -608,6 +614,7 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
       }
     }
   }
+  stamp(7);
   if (want_stats) {   // wave-uniform: EXEC is all ones for the transposed reads
     const unsigned char* cw = ct + (wm * 64) * Cfg::CLD + (wn * 64) * (int)sizeof(T);   // this wave's own block: no barrier needed
 #pragma unroll
@@ -662,9 +669,7 @@ __global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const
   stamp(3);
   store_tile<T, TW, TPIX, BN, NT, Cfg::CLD, BNR>(a, ct, n, y0, x0, n0, t, tile, ntiles);
   stamp(4);
-  if (a.dbg && t == 0) {
-    a.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-  }
+  stamp(6);
 }
 
 template <typename T, int TW, int TH, int BN, int HB, int NS, bool BNR, bool LAZY>
@@ -787,7 +792,15 @@ static int launch_hg_t(int tp, const ConvArgs& a, hipStream_t s) {
   return n128 ? launch_hg_cfg<T, 16, 16, 128, 2>(a, s) : launch_hg_cfg<T, 16, 16, 64, 1>(a, s);
 }
 
-void set_debug_buffer(void* p) { g_debug_buffer = p; }
+int set_debug_buffer(void* p) {
+#ifdef FLAIR_HG_STAMPS
+  g_debug_buffer = p;
+  return 0;
+#else
+  (void)p;
+  return -7;   // not a diagnostic build
+#endif
+}
 
 int launch_conv_hg(int dtype, const ConvArgs& a, hipStream_t s) {
   const int tp = hg_tile_pixels(dtype, a);

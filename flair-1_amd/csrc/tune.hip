@@ -28,12 +28,9 @@ int tune(const char* key, int dflt) {
 void tune_set(const char* key, int value) { table()[key] = value; }
 }  // namespace flair
 
-namespace flair { void set_debug_buffer(void* p); }
+namespace flair { int set_debug_buffer(void* p); }
 
-extern "C" int flair_debug_buffer(void* p) {
-  flair::set_debug_buffer(p);
-  return 0;
-}
+extern "C" int flair_debug_buffer(void* p) { return flair::set_debug_buffer(p); }
 
 extern "C" int flair_tune_set(const char* key, int value) {
   if (!key) return -1;

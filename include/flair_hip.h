@@ -214,7 +214,9 @@ int flair_profile_kernel(int i, char* name, int name_cap, double* total_ms, int6
  * variables DESIGN.md lists, the environment supplies the default).  Returns 0. */
 int flair_tune_set(const char* key, int value);
 /* Diagnostic: device buffer of [workgroups][8] uint64 that the next halo-GEMM launches fill with s_memtime stamps
- * (kernel start, main loop start, main loop end, accumulators staged, stored); NULL switches it off.  Returns 0. */
+ * (kernel start, main loop start, main loop end, accumulators staged, stored; + 100 MHz real-time start / end); NULL
+ * switches it off.  Only the diagnostic build (FLAIR_STAMPS=1 python flair-1_amd/build.py) contains the stamps: the shipped
+ * library returns -7 and its kernels execute none. */
 int flair_debug_buffer(void* device_u64);
 
 #ifdef __cplusplus

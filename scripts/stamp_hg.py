@@ -1,5 +1,6 @@
 """Phase anatomy of the halo-GEMM kernel: per-workgroup s_memtime stamps (flair_debug_buffer) -> cycles spent in the
-prologue (halo + first weight tiles), the tap loop, accumulator staging and the tile store.  Diagnostics only."""
+prologue (halo + first weight tiles), the tap loop, accumulator staging and the tile store.  Diagnostics only: needs the
+stamp build (FLAIR_STAMPS=1 python flair-1_amd/build.py --force); the shipped library has no stamps."""
 import os
 import sys
 
@@ -25,7 +26,7 @@ for name, H, C0, C1, up0, Cout in SHAPES:
     for _ in range(3):
         ops.conv2d_forward(x0, w, x1=x1, up0=bool(up0), want_stats=True)
     buf = torch.zeros(8192, 8, dtype=torch.int64, device=dev)
-    L.lib().flair_debug_buffer(L.ptr(buf))
+    L.check(L.lib().flair_debug_buffer(L.ptr(buf)), "flair_debug_buffer (diagnostic build needed)")
     ops.conv2d_forward(x0, w, x1=x1, up0=bool(up0), want_stats=True)
     torch.cuda.synchronize()
     L.lib().flair_debug_buffer(None)
@@ -43,5 +44,6 @@ for name, H, C0, C1, up0, Cout in SHAPES:
     late = int((starts > 0.25 * span_us).sum())
     print(f"    realtime: kernel span {span_us:6.1f} us, median WG lifetime {float((rt1 - rt0).median()) / 100.0:6.1f} us, in-kernel clock {clk:6.0f} MHz, "
           f"WGs starting after 25% of the span: {late}")
+    print(f"    staging writes done {med(s[:, 7] - s[:, 2]):6.0f} cyc after the loop; statistics + barrier {med(s[:, 3] - s[:, 7]):6.0f}")
     print(f"{name:20s} {n} WGs  total {med(tot):8.0f} cyc | prologue {med(d[0]):7.0f} | loop {med(d[1]):8.0f} = {med(d[1]) / (9 * nch):6.0f}/tap "
           f"| stage {med(d[2]):6.0f} | store {med(d[3]):6.0f} | span(max end - min start) {float(s[:, 4].max() - s[:, 0].min()):9.0f}", flush=True)
