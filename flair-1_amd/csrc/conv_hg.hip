@@ -304,7 +304,8 @@ struct HgdCfg {
   static constexpr int CK = 8 * CH;
   static constexpr int TPIX = TW * TH;
   static constexpr int HW_ = TW + 2, HH = TH + 2, HPIX = HW_ * HH;
-  static constexpr int WMN = TPIX / 64, WNN = BN / 64;
+  static constexpr int WMN = TPIX / 64, WNN = BN >= 64 ? BN / 64 : 1;   // BN = 32: one wave column of two 16-wide blocks
+  static constexpr int TN = BN / 16 / WNN;
   static constexpr int NWAVE = WMN * WNN;
   static constexpr int NT = 64 * NWAVE;
   static constexpr int HALO = HPIX * 128;
@@ -336,10 +337,10 @@ __device__ __forceinline__ void wait_vm_lgkm0(int n) {
 }
 
 template <typename T, int TW, int TH, int BN, int HB, int NS, bool BNR, bool LAZY>
-__global__ __launch_bounds__(TW * TH * BN / 64, 2) void conv3x3_hgd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(TW * TH * (BN >= 64 ? BN : 64) / 64, 2) void conv3x3_hgd_kernel(const ConvArgs a) {
   using Cfg = HgdCfg<T, TW, TH, BN, HB, NS>;
   constexpr int CH = Cfg::CH, CK = Cfg::CK, HW_ = Cfg::HW_, HPIX = Cfg::HPIX, NT = Cfg::NT, TPIX = Cfg::TPIX;
-  constexpr int TM = 4, TN = 4, MTX = TW / 16, DPW = Cfg::DPW, D = Cfg::D, HITEMS = Cfg::HITEMS;
+  constexpr int TM = 4, TN = Cfg::TN, MTX = TW / 16, DPW = Cfg::DPW, D = Cfg::D, HITEMS = Cfg::HITEMS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* halo0 = smem;
   unsigned char* bt0 = smem + HB * Cfg::HALO;
@@ -691,8 +692,9 @@ int launch_hgd_cfg_b(const ConvArgs& a, hipStream_t s) {
     const double flops = 2.0 * (double)M * a.Cout * a.Kg;
     const double bytes = ((double)M / (a.up0 ? 4 : 1) * a.C0 + (double)M * a.C1 + (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) +
                          (double)a.Cout * a.Kg * sizeof(T);
-    static const char* names[2][2] = {{"conv3x3_hg_f32_n64", "conv3x3_hg_f32_n128"}, {"conv3x3_hg_bf16_n64", "conv3x3_hg_bf16_n128"}};
-    ProfScope ps(names[sizeof(T) == 2][BN == 128], flops, bytes, s);
+    static const char* names[2][3] = {{"conv3x3_hg_f32_n32", "conv3x3_hg_f32_n64", "conv3x3_hg_f32_n128"},
+                                      {"conv3x3_hg_bf16_n32", "conv3x3_hg_bf16_n64", "conv3x3_hg_bf16_n128"}};
+    ProfScope ps(names[sizeof(T) == 2][BN == 128 ? 2 : BN == 64 ? 1 : 0], flops, bytes, s);
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::SMEM, s, b);
   }
   FLAIR_CHECK_LAUNCH();
@@ -701,9 +703,13 @@ int launch_hgd_cfg_b(const ConvArgs& a, hipStream_t s) {
 
 template <typename T, int TW, int TH, int BN, int HB, int NS>
 int launch_hgd_cfg(const ConvArgs& a, hipStream_t s) {
-  if (a.in_scale) return a.bnr_partial ? -6 : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, true>(a, s);
-  return a.bnr_partial ? launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, true, false>(a, s)
-                       : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, false>(a, s);
+  if constexpr (BN == 32) {   // forward of decoder block 3 conv1 only: no lazy input, no fused data-gradient epilogue
+    return (a.in_scale || a.bnr_partial) ? -6 : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, false>(a, s);
+  } else {
+    if (a.in_scale) return a.bnr_partial ? -6 : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, true>(a, s);
+    return a.bnr_partial ? launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, true, false>(a, s)
+                         : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, false>(a, s);
+  }
 }
 
 int g_hg_variant = -1;  // tuning override (FLAIR_HG_VARIANT): 0 = 256 px x 8 waves, 1 = 128 px x 4 waves x 2 WG/CU
@@ -770,7 +776,12 @@ bool conv_hg_applicable(int dtype, const ConvArgs& a) {
   if (a.R != 3 || a.S != 3 || a.out_mul != 1 || a.in_div != 1 || a.pad != 1) return false;
   if (a.Hout != a.Hin || a.Wout != a.Win || a.out_nchw || !a.out) return false;
   if (a.in_scale && (hg_dma_mode() == 0 || a.bnr_partial)) return false;
-  if ((Cin % ck) || (a.C0 % ck) || a.Cout < 64 || (a.Cout % 64)) return false;
+  if ((Cin % ck) || (a.C0 % ck)) return false;
+  // 32 output channels (decoder block 3 conv1, 128 -> 32 at 256^2: 155 GFLOP on the ridge): the LDS-DMA kernel with one
+  // 32-wide column block on 256-pixel tiles; no fused data-gradient epilogues there
+  if (a.Cout == 32) return hg_dma_mode() != 0 && tune("FLAIR_HG_N32", 1) != 0 && !a.bnr_partial && !a.in_scale && a.pool_c0 == 0 &&
+                           ((a.Wout % 32 == 0 && a.Hout % 8 == 0) || (a.Wout % 16 == 0 && a.Hout % 16 == 0));
+  if (a.Cout < 64 || (a.Cout % 64)) return false;
   return hg_tile_pixels(dtype, a) != 0;
 }
 
@@ -780,6 +791,10 @@ template <typename T>
 static int launch_hg_t(int tp, const ConvArgs& a, hipStream_t s) {
   const bool n128 = (a.Cout % 128) == 0;
   const int dma = hg_dma_mode();
+  if (a.Cout == 32) {
+    if (a.Wout % 32 == 0) return launch_hgd_cfg<T, 32, 8, 32, 1, 3>(a, s);
+    return launch_hgd_cfg<T, 16, 16, 32, 1, 3>(a, s);
+  }
   // fp32 (parity mode) is MFMA-bound at 1/16 of the bf16 rate: the register-staged kernel is as fast there; the LDS-DMA
   // kernel serves it only for a lazy BatchNorm + ReLU input
   if (dma != 0 && (sizeof(T) == 2 || a.in_scale)) {

@@ -83,6 +83,17 @@ def test_conv_upsample_concat_bias_head(dev, dtype):
     got = y.float().cpu().permute(0, 3, 1, 2)
     assert _rel(got, ref) < TOL[dtype]
     assert _rel(st[0].cpu(), got.sum(dim=(0, 2, 3))) < 1e-4
+    # decoder block 3 conv1 shape (64 upsampled + 64 skip -> 32): the 32-wide column block of the LDS-DMA halo-GEMM,
+    # on both of its tile shapes (32x8 and 16x16)
+    for hh, ww in ((8, 32), (16, 16)):
+        x0 = _q(torch.randn(2, 64, hh // 2, ww // 2, generator=g), dtype)
+        x1 = _q(torch.randn(2, 64, hh, ww, generator=g), dtype)
+        w = torch.randn(32, 128, 3, 3, generator=g) / 34
+        ref = F.conv2d(torch.cat([F.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1), _q(w, dtype), padding=1)
+        y, _, st = ops.conv2d_forward(_nhwc(x0, dtype, dev), w.to(dev), x1=_nhwc(x1, dtype, dev), up0=True, want_stats=True)
+        got = y.float().cpu().permute(0, 3, 1, 2)
+        assert _rel(got, ref) < TOL[dtype]
+        assert _rel(st[0].cpu(), got.sum(dim=(0, 2, 3))) < 1e-4 and _rel(st[1].cpu(), (got * got).sum(dim=(0, 2, 3))) < 1e-4
     xh = _q(torch.randn(2, 16, 32, 32, generator=g), dtype)
     wh = torch.randn(13, 16, 3, 3, generator=g) / 12
     bh = torch.randn(13, generator=g)
