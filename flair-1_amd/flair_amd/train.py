@@ -111,6 +111,10 @@ class SegTrainer:
     def train_step(self, img, labels):
         """img (B,Cin,H,W) fp32 HIP tensor; labels (B,H,W) uint8/int or fp32 one-hot (B,C,H,W).  Returns the
         device scalar loss (no host sync)."""
+        with torch.cuda.device(self.grads.device):   # every native call below launches on the current device's stream
+            return self._train_step(img, labels)
+
+    def _train_step(self, img, labels):
         m = self.model
         B, _, H, W = img.shape
         ld = self._buffers(B, H, W)
@@ -143,6 +147,10 @@ class SegTrainer:
         """predict_step of the reference (task_module.py:206-213): (B,H,W) uint8 argmax(softmax(logits))."""
         m = self.model
         B, _, H, W = img.shape
+        with torch.cuda.device(self.grads.device):
+            return self._predict(m, img, B, H, W)
+
+    def _predict(self, m, img, B, H, W):
         m._c_forward(img, training=False, want_logits=False)   # logits stay NHWC in the workspace
         preds = torch.empty(B, H, W, dtype=torch.uint8, device=img.device)
         l = L.lib()

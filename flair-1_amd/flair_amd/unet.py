@@ -29,6 +29,28 @@ import torch.nn as nn
 from . import _lib as L
 
 
+def _on_model_device(fn):
+    """Native calls launch on the CURRENT device's stream and the library's internal streams / events are created on the
+    current device: run them with the model's device current (a model on cuda:1 while cuda:0 is current — two replicas in
+    one process, a forgotten set_device — would otherwise launch on the wrong device's stream), and refuse inputs that
+    live elsewhere."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = self._flat_p.device if getattr(self, "_flat_p", None) is not None else None
+        if dev is None or dev.type != "cuda":
+            return fn(self, *args, **kwargs)
+        for a in args:
+            ts = a if isinstance(a, (list, tuple)) else (a,)
+            for t in ts:
+                if torch.is_tensor(t) and t.is_cuda and t.device != dev:
+                    raise L.FlairHipError(f"tensor on {t.device} passed to a model on {dev}")
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    return wrapper
+
+
 # ------------------------------------------------------------------------------------------------ containers
 class _BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride, downsample):
@@ -410,6 +432,7 @@ class Unet(nn.Module):
         """num_batches_tracked += 1 for BatchNorm layers [lo, hi) (one op on the flat int64 buffer)."""
         self._flat_n[lo:hi] += 1
 
+    @_on_model_device
     def _c_forward(self, x, training, want_logits=True):
         """want_logits=False (fused trainer): the head's output stays in the workspace as NHWC rows of the compute dtype
         (flair_unet_logits_nhwc) and no fp32 NCHW tensor is produced; returns None."""
@@ -435,6 +458,7 @@ class Unet(nn.Module):
         self._grads = torch.zeros(self._n_params, dtype=torch.float32, device=self._flat_p.device)
         return self._grads
 
+    @_on_model_device
     def _c_backward(self, dlogits=None, dlogits_nhwc=None, grads=None, stage_events=None):
         ws = self._live_ws
         grads = grads if grads is not None else self._new_grads()
@@ -446,6 +470,7 @@ class Unet(nn.Module):
         return grads
 
     # ---- split path (model.py:57-62)
+    @_on_model_device
     def _c_encoder_forward(self, x, training):
         x = self._prep(x)
         B, _, H, W = x.shape
@@ -467,6 +492,7 @@ class Unet(nn.Module):
             self._bump_bn(0, 36)
         return feats
 
+    @_on_model_device
     def _c_decoder_forward(self, feats, training):
         (B, H, W), ws = self._split[bool(training)]
         feats = [f.detach().to(torch.float32).contiguous() for f in feats]
@@ -478,6 +504,7 @@ class Unet(nn.Module):
             self._bump_bn(36, 46)
         return out
 
+    @_on_model_device
     def _c_head_forward(self, x, training):
         (B, H, W), ws = self._split[bool(training)]
         x = x.detach().to(torch.float32).contiguous()
@@ -491,6 +518,7 @@ class Unet(nn.Module):
             self._new_grads()
         return self._grads
 
+    @_on_model_device
     def _c_head_backward(self, dlogits):
         B, H, W = self._split_shape
         ws = self._split_ws
@@ -500,6 +528,7 @@ class Unet(nn.Module):
                                                  ws.numel(), L.stream()), "head_backward")
         return dx
 
+    @_on_model_device
     def _c_decoder_backward(self, dout):
         B, H, W = self._split_shape
         ws = self._split_ws
@@ -511,6 +540,7 @@ class Unet(nn.Module):
                                                     ws.numel(), L.stream()), "decoder_backward")
         return dfe
 
+    @_on_model_device
     def _c_encoder_backward(self, dfeats):
         ws = self._split_ws
         g = self._split_grads()
