@@ -103,6 +103,10 @@ class UNet {
   int encoder_backward(const float* params, const float* const dfeats_nchw[5], float* grads, void* ws,
                        size_t ws_bytes, hipStream_t s);
 
+  // Inference with constant weights: when the caller vouches that parameters and buffers are unchanged since the previous
+  // eval-mode forward on this handle, the next eval-mode forward with the same arena and shape skips the weight pack and
+  // the 46 BatchNorm-coefficient launches (both still sit in the arena at the same offsets).  One-shot: cleared by forward.
+  void reuse_constants(bool on) { reuse_req_ = on; }
   void* last_dlogits_nhwc() const { return dl_nhwc_; }
   const void* logits_nhwc() const { return logits_nhwc_; }
   int head_ld() const { return 16 > classes ? 16 : (int)round_up(classes, 8); }
@@ -129,6 +133,9 @@ class UNet {
   int enc_units_end_ = 0, dec_units_begin_ = 0;
   size_t fwd_top_ = 0;      // arena top after forward (backward scratch starts here)
   bool packed_d_ = false;
+  bool reuse_req_ = false, reuse_ = false, last_valid_ = false;
+  const void* last_ws_ = nullptr;
+  int last_B_ = 0, last_H_ = 0, last_W_ = 0;
   bool lazy_ok_ = false;
   int lazy_max_c_ = 16;    // widest unit that hands out a lazy activation (FLAIR_LAZY_BN=2: 32)
   // weight-gradient kernels run on an internal side stream, forked from / joined to the caller's stream with events, so

@@ -325,8 +325,9 @@ int UNet::run_unit(int ci, int bi, const Act& in0, const Act& in1, bool up0, boo
   if (!training_) {
     // inference: BatchNorm (running statistics) is a per-channel affine -> folded, together with the residual
     // add and the ReLU, into the conv epilogue; the pre-BN tensor is never written
-    RUN(bn_eval_coeffs(b.C, params_ + b.g_off, params_ + b.b_off, buffers_ + b.rm_off, buffers_ + b.rv_off, 1e-5f,
-                       u.scale, u.shift, s_));
+    if (!reuse_)   // constant weights: the coefficients of the previous eval forward are still at u.scale / u.shift
+      RUN(bn_eval_coeffs(b.C, params_ + b.g_off, params_ + b.b_off, buffers_ + b.rm_off, buffers_ + b.rv_off, 1e-5f,
+                         u.scale, u.shift, s_));
     u.out = u.y;
     a.oscale = u.scale; a.oshift = u.shift; a.orelu = relu ? 1 : 0;
     a.ores = res_unit >= 0 ? units_[res_unit].out.p : res.p;
@@ -440,16 +441,21 @@ void UNet::head_fwd_impl(float* logits_nchw) {
 int UNet::forward(const float* params, float* buffers, const float* x_nchw, float* logits_nchw, int B, int H, int W,
                   int training, void* ws, size_t ws_bytes, hipStream_t s) {
   if ((H % 32) || (W % 32)) return -10;
+  reuse_ = reuse_req_ && !training && last_valid_ && ws == last_ws_ && B == last_B_ && H == last_H_ && W == last_W_;
+  reuse_req_ = false;
   begin(ws, ws_bytes, s, false);
   fwd_common_begin(params, buffers, B, H, W, training);
   const int lazy_env = tune("FLAIR_LAZY_BN", 1);
   lazy_ok_ = lazy_env != 0;
   lazy_max_c_ = lazy_env >= 2 ? 32 : 16;
-  pack_forward_weights();
+  if (!reuse_) pack_forward_weights();
   encoder_fwd_impl(x_nchw);
   decoder_fwd_impl();
   head_fwd_impl(logits_nchw);
   fwd_top_ = top_;
+  reuse_ = false;
+  last_valid_ = !training && !err_;   // (a training forward lays the arena out differently)
+  last_ws_ = ws; last_B_ = B; last_H_ = H; last_W_ = W;
   return err_;
 }
 

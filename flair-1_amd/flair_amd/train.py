@@ -140,6 +140,7 @@ class SegTrainer:
                 allreduce_buckets(self.grads, self.buckets, self.group)
         # DDP averages: fold 1/world into the step size
         ops.sgd_step_(m._flat_p, self.grads, self.lr / self.world)
+        m._native_writes = m.__dict__.get("_native_writes", 0) + 1   # parameters changed behind torch's version counter
         return self.loss
 
     @torch.no_grad()

@@ -440,7 +440,21 @@ class Unet(nn.Module):
         B, _, H, W = x.shape
         ws = self._workspace(B, H, W, training)
         logits = torch.empty(B, self.classes, H, W, dtype=torch.float32, device=x.device) if want_logits else None
-        L.check(L.lib().flair_unet_forward(self._hh(training), L.ptr(self._flat_p), L.ptr(self._flat_b), L.ptr(x), L.ptr(logits), B, H, W,
+        h = self._hh(training)
+        if not training:
+            # constant weights between two eval forwards (predict / zone_detect loops): skip the weight pack and the
+            # BatchNorm-coefficient launches.  torch bumps a tensor's _version on every in-place write (optimizers,
+            # load_state_dict; writes through .data are invisible to it, as they are to autograd); native writers (training forwards: running statistics; the fused
+            # trainer's SGD) bump _native_writes.
+            # (the parameters / buffers are .data views of the flat buffers: each carries its own version counter)
+            ver = sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
+            key = (ver, self._flat_p._version, self._flat_b._version, self.__dict__.get("_native_writes", 0), B, H, W, ws.data_ptr())
+            if self.__dict__.get("_eval_key") == key:
+                L.check(L.lib().flair_unet_reuse_constants(h, 1), "flair_unet_reuse_constants")
+            self._eval_key = key
+        else:
+            self._native_writes = self.__dict__.get("_native_writes", 0) + 1
+        L.check(L.lib().flair_unet_forward(h, L.ptr(self._flat_p), L.ptr(self._flat_b), L.ptr(x), L.ptr(logits), B, H, W,
                                            int(training), L.ptr(ws), ws.numel(), L.stream()), "flair_unet_forward")
         if training:
             self._fwd_id += 1
@@ -480,6 +494,8 @@ class Unet(nn.Module):
         arr = (C.c_void_p * 5)(*[f.data_ptr() for f in feats])
         L.check(L.lib().flair_unet_encoder_forward(self._hh(training), L.ptr(self._flat_p), L.ptr(self._flat_b), L.ptr(x), arr, B, H, W,
                                                    int(training), L.ptr(ws), ws.numel(), L.stream()), "encoder_forward")
+        if training:
+            self._native_writes = self.__dict__.get("_native_writes", 0) + 1   # running statistics are about to change
         # per mode: an eval-mode split forward must not disturb a training one that still awaits its backward
         self.__dict__.setdefault("_split", {})[bool(training)] = ((B, H, W), ws)
         if training:
@@ -501,6 +517,7 @@ class Unet(nn.Module):
         L.check(L.lib().flair_unet_decoder_forward(self._hh(training), L.ptr(self._flat_p), L.ptr(self._flat_b), arr, L.ptr(out), B, H, W,
                                                    int(training), L.ptr(ws), ws.numel(), L.stream()), "decoder_forward")
         if training:
+            self._native_writes = self.__dict__.get("_native_writes", 0) + 1   # decoder running statistics changed
             self._bump_bn(36, 46)
         return out
 
@@ -599,7 +616,7 @@ class Unet(nn.Module):
         except Exception:
             pass
 
-    _NATIVE_STATE = ("_h", "_h_eval", "_ws_need", "_split", "_ws", "_flat_p", "_flat_b", "_flat_n", "_grads", "_live_ws", "_split_ws")
+    _NATIVE_STATE = ("_h", "_h_eval", "_eval_key", "_ws_need", "_split", "_ws", "_flat_p", "_flat_b", "_flat_n", "_grads", "_live_ws", "_split_ws")
 
     def __getstate__(self):
         d = dict(self.__dict__)

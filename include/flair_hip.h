@@ -57,6 +57,12 @@ int flair_unet_backward(flair_unet_t* h, const float* params, const float* dlogi
                         float* grads, void* workspace, size_t workspace_bytes, void* stream,
                         void* const* stage_events);
 int flair_unet_head_ld(const flair_unet_t* h);
+/* Inference with constant weights (zone_detect's window loop, predict): a one-shot promise that `params` and `buffers` are
+ * bit-identical to those of the previous eval-mode flair_unet_forward on this handle.  If the next eval-mode forward also
+ * uses the same workspace and shape, it skips re-packing the weights and re-deriving the 46 BatchNorm affine pairs (both
+ * are still in the workspace); any other call clears the promise.  The reference has no counterpart: PyTorch modules keep
+ * their weights in the layout they compute in. */
+int flair_unet_reuse_constants(flair_unet_t* h, int on);
 
 /* seg_model.encoder(x) / .decoder(*feats) / .segmentation_head(t) — the metadata path model.py:57-62.
  * feats[i] = feature i+1 of the encoder, NCHW fp32: (B,64,H/2,W/2) ... (B,512,H/32,W/32). */

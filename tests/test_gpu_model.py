@@ -604,3 +604,50 @@ def test_metadata_mlp_kernel_matches_reference_module(dev):
     (h * w).sum().backward()
     for p, r in zip(hip.parameters(), ref):
         assert float((p.grad.cpu() - r.grad).abs().max()) <= 1e-5 * max(1.0, float(r.grad.abs().max()))
+
+
+def test_constant_weight_reuse_in_eval_loops_is_invalidated_by_every_writer(dev):
+    """Eval forwards with unchanged weights skip the weight pack and the BatchNorm-coefficient launches
+    (flair_unet_reuse_constants).  Same outputs as a cold forward, and every way the weights can change between two
+    eval forwards — torch in-place writes, load_state_dict, a training forward (running statistics), the fused
+    trainer's native SGD — is noticed."""
+    import flair_amd
+    ref, hip = _pair(5, 13, 11, dev)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 5, 64, 64, generator=g).to(dev)
+    y = torch.randn(2, 5, 64, 64, generator=g).to(dev)
+    lab = torch.randint(0, 13, (2, 64, 64), generator=g).to(torch.uint8).to(dev)
+    hip.eval()
+
+    def cold(inp):   # a fresh model holding the same state: never reuses anything
+        m = flair_amd.create_model("unet", "resnet34", encoder_weights=None, in_channels=5, classes=13, compute_dtype="f32")
+        m.load_state_dict(hip.state_dict())
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            return m(inp)
+
+    with torch.no_grad():
+        a = hip(x)
+        b = hip(y)            # second eval forward: constants reused
+        assert torch.equal(b, cold(y)) and torch.equal(hip(x), a)
+        # 1. torch in-place write to a parameter
+        next(iter(hip.parameters())).mul_(1.5)
+        assert torch.equal(hip(y), cold(y))
+        # 2. load_state_dict
+        hip.load_state_dict(ref.state_dict())
+        assert torch.equal(hip(y), cold(y))
+    # 3. a training forward moves the running statistics natively
+    hip.train()
+    with torch.no_grad():
+        hip(x)
+    hip.eval()
+    with torch.no_grad():
+        assert torch.equal(hip(y), cold(y))
+    # 4. the fused trainer's SGD writes the parameters natively
+    tr = flair_amd.SegTrainer(hip.train(), lr=0.05)
+    p0 = tr.predict(y)
+    tr.train_step(x, lab)
+    hip.eval()
+    with torch.no_grad():
+        assert torch.equal(hip(y), cold(y))
+    assert p0.shape == (2, 64, 64)
