@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflair_hip.so")
+LIB_PATH = os.environ.get("FLAIR_HIP_LIB") or os.path.join(_HERE, "libflair_hip.so")   # override: A/B of two builds on one box
 
 _lib = None
 
