@@ -452,6 +452,37 @@ def test_training_step_is_bit_reproducible(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_step_does_not_see_the_previous_steps_partial_sums(dev, dtype):
+    """The arena hands out the same addresses every step (partial sums, slabs, packed weights, gradient buffers): anything
+    read before it is rewritten would show the PREVIOUS step's data.  With lr = 0 the gradients of batch Y must be
+    bit-identical whether or not a different batch X went through the model first (and on a second model that never saw
+    X).  (Written for an in-launch BatchNorm-backward finalize that was measured and dropped; kept as a
+    guard for every two-stage reduction.)"""
+    import flair_amd
+    _, a = _pair(5, 13, 9, dev, dtype)
+    _, b = _pair(5, 13, 9, dev, dtype)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 5, 128, 192, generator=g).to(dev) * 3.0
+    y = torch.randn(4, 5, 128, 192, generator=g).to(dev)
+    lx = torch.randint(0, 13, (4, 128, 192), generator=g).to(torch.uint8).to(dev)
+    ly = torch.randint(0, 13, (4, 128, 192), generator=g).to(torch.uint8).to(dev)
+    ta = flair_amd.SegTrainer(a.train(), lr=0.0)
+    tb = flair_amd.SegTrainer(b.train(), lr=0.0)
+    for _ in range(3):
+        ta.train_step(x, lx)      # model a has X's partial sums in its arena
+    ta.train_step(y, ly)
+    tb.train_step(y, ly)
+    torch.cuda.synchronize()
+    assert ta.loss.item() == tb.loss.item()
+    assert torch.equal(ta.grads, tb.grads)
+    for _ in range(2):            # and alternating, in one arena
+        ta.train_step(x, lx)
+        ta.train_step(y, ly)
+        torch.cuda.synchronize()
+        assert torch.equal(ta.grads, tb.grads)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_full_size_step_properties(dev, dtype):
     """BASELINE configuration (32 x 5 x 512 x 512, 13 classes), checked through size-independent properties:
     a batch made of the same 16 tiles twice gives pairwise identical masks (every per-pixel reduction has a fixed order
