@@ -159,6 +159,8 @@ struct WgradArgs {
   int accumulate;
   const float* in_scale;                             // optional lazy BN + ReLU on x (see ConvArgs::in_scale);
   const float* in_shift;                             // small-channel halo kernel only
+  int cus;                                           // persistent workgroups (= CUs) the register-resident kernel may occupy;
+                                                     // 0 = the whole chip.  The executor gives its side stream half of it.
 };
 int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);
 size_t wgrad_workspace_bytes(int dtype, const WgradArgs& a);

@@ -147,7 +147,8 @@ class UNet {
   size_t fork_next_ = 0;
   bool side_pending_ = false;
   bool side_init();
-  hipStream_t wgrad_stream();   // forks the side stream behind everything queued on s_ so far
+  hipStream_t wgrad_stream();
+  int side_cus(int unit) const;   // forks the side stream behind everything queued on s_ so far
   void side_join();
  public:
   ~UNet();

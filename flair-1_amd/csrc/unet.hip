@@ -149,6 +149,17 @@ bool UNet::side_init() {
   return hipEventCreateWithFlags(&join_ev_, hipEventDisableTiming) == hipSuccess;
 }
 
+// Space sharing instead of time sharing: on the side stream the persistent weight-gradient kernel takes only HALF of the
+// CUs (FLAIR_WG_CUS, 128), for twice as long.  The caller's stream always finds free CUs — its BatchNorm kernels, HBM-bound,
+// lose little on the other half and no longer queue behind 256 persistent workgroups (the "35 us bn_bwd_finalize" of the
+// round-2 trace) — and half the workgroups means half the fp32 slabs (75 -> 37 MB written and re-read per launch).
+// Step 13.2 -> 12.4 ms (192 CUs: 12.55, 144: 12.48, 112: 12.56, 96: 12.87; giving the last units of backward, when the
+// caller's stream runs dry, the whole chip again: +0.05 ... +0.3 ms).
+int UNet::side_cus(int) const {
+  if (!tune("FLAIR_WGRAD_STREAM", 1)) return 0;
+  return tune("FLAIR_WG_CUS", 128);
+}
+
 hipStream_t UNet::wgrad_stream() {
   if (dry_ || err_ || !side_init()) return s_;
   hipEvent_t e = fork_ev_[fork_next_++ % fork_ev_.size()];
@@ -596,6 +607,7 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
   w.dy = dy; w.dy_ld = u.y.C; w.Cout = c.Cout;
   w.dw = grads_ + c.w_off; w.Cin_real = c.Cin; w.accumulate = 0;
   w.in_scale = u.in0.lz_scale; w.in_shift = u.in0.lz_shift;
+  w.cus = side_cus(ui);
   w.partial = (float*)alloc(wgrad_workspace_bytes(dtype, w));
   {
     hipStream_t ws = wgrad_stream();   // dy is complete on s_; nothing later on s_ writes what this kernel reads

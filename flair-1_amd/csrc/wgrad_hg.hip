@@ -388,7 +388,7 @@ static bool wg_big_geom(int dtype, const WgradArgs& a, int& nsplit, int& kg) {
   if ((Cin % ck) || (a.C0 % ck) || (a.Cout % co) || a.dy_ld != a.Cout) return false;
   const long ntiles = (long)a.N * a.Hin * a.Win / TPIX;
   const int per = (Cin / ck) * (a.Cout / co);
-  long ns = 256 / per;            // one 8-wave workgroup per CU
+  long ns = (a.cus > 0 ? a.cus : 256) / per;   // one 8-wave workgroup per CU
   if (ns < 1) ns = 1;
   if (ns > ntiles) ns = ntiles;
   nsplit = (int)ns;
