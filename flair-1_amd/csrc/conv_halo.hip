@@ -10,6 +10,7 @@
 #include "common.h"
 #include "prof.h"
 #include "tile_store.h"
+#include "tune.h"
 
 namespace flair {
 namespace {
@@ -328,9 +329,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
     s1[q] = 0.f; s2[q] = 0.f;
   }
 
-  u32x4 hreg[Cfg::HITEMS];
-  unsigned hbits = 0;
-  auto halo_load = [&](int tile) {
+  // Two register slots: the halo of tile i + 2 is requested while tile i is multiplied (the MFMA phase of a 16-32-channel tile
+  // is ~0.3 us, an HBM round trip under load ~2 us: with one slot every iteration waited for its loads)
+  u32x4 hregA[Cfg::HITEMS], hregB[Cfg::HITEMS];
+  unsigned hbitsA = 0, hbitsB = 0;
+  auto halo_load = [&](int tile, u32x4 (&hreg)[Cfg::HITEMS], unsigned& hbits) {
     const bool tok = tile < ntiles;
     const int tl = tok ? tile : 0;
     const int n = tl / (tiles_x * tiles_y);
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
     }
     hbits = hb;
   };
-  auto halo_store = [&]() {
+  auto halo_store = [&](const u32x4 (&hreg)[Cfg::HITEMS], unsigned hbits) {
 #pragma unroll
     for (int k = 0; k < Cfg::HITEMS; ++k) {
       const int it = t + 256 * k;
@@ -362,11 +365,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
     }
   };
 
-  halo_load(blockIdx.x);
-  halo_store();
+  halo_load(blockIdx.x, hregA, hbitsA);
+  halo_load(blockIdx.x + gridDim.x, hregB, hbitsB);
+  halo_store(hregA, hbitsA);
   __syncthreads();
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    halo_load(tile + gridDim.x);          // next tile rides in registers through this tile's MFMAs
+  // one tile: request tile + 2 strides into the slot that is free (`ld`), multiply, stage the next tile from the other (`st`)
+  auto do_tile = [&](int tile, u32x4 (&ld)[Cfg::HITEMS], unsigned& ldbits, const u32x4 (&stg)[Cfg::HITEMS], const unsigned& stbits) {
+    halo_load(tile + 2 * gridDim.x, ld, ldbits);
     __builtin_amdgcn_sched_barrier(0);
     f32x4_t acc[TM][TN];
 #pragma unroll
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
       }
     }
     __syncthreads();   // every wave is done with the halo, the C tile is complete
-    halo_store();
+    halo_store(stg, stbits);
     {
       const int n = tile / (tiles_x * tiles_y);
       const int trem = tile - n * tiles_x * tiles_y;
@@ -429,6 +434,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
       }
     }
     __syncthreads();   // next halo visible, C tile free
+  };
+  for (int tile = blockIdx.x; tile < ntiles; tile += 2 * gridDim.x) {
+    do_tile(tile, hregA, hbitsA, hregB, hbitsB);   // slot A went to LDS before this tile; B holds the next one
+    if (tile + gridDim.x < ntiles) do_tile(tile + gridDim.x, hregB, hbitsB, hregA, hbitsA);
   }
   if (a.stats) {
 #pragma unroll
@@ -451,12 +460,31 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
   }
 }
 
+// persistent grid = the workgroups that are resident at once (registers and LDS: asked from the runtime once per variant; a
+// grid above that runs its surplus as a second, unbalanced round — 16 -> 16 at 512^2: 141 us with 4 per CU against 125 with the
+// 3 that fit).  Without a device (planning on a CPU-only host) the LDS bound stands in.
+template <typename T, int CK, int BN, bool LZ>
+int halo_p_per_cu() {
+  static const int per_cu = [] {
+    int lds = (160 * 1024) / HaloPCfg<T, CK, BN>::SMEM;
+    lds = lds > 4 ? 4 : (lds < 1 ? 1 : lds);
+    int nb = 0;
+    auto kern = conv3x3_halo_p_kernel<T, CK, BN, LZ>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HaloPCfg<T, CK, BN>::SMEM) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, HaloPCfg<T, CK, BN>::SMEM) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      return lds;
+    }
+    return nb > 8 ? 8 : nb;
+  }();
+  const int cap = tune("FLAIR_HALO_P_WGS", 0);
+  return cap > 0 && cap < per_cu ? cap : per_cu;
+}
+
 template <typename T, int CK, int BN>
 int halo_p_blocks(const ConvArgs& a) {
   const long ntiles = (long)a.N * a.Hout * a.Wout / (TH * TW);
-  int per_cu = (160 * 1024) / HaloPCfg<T, CK, BN>::SMEM;
-  per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
-  const long cap = 256L * per_cu;
+  const long cap = 256L * (a.in_scale ? halo_p_per_cu<T, CK, BN, true>() : halo_p_per_cu<T, CK, BN, false>());
   return (int)(ntiles < cap ? ntiles : cap);
 }
 
@@ -490,10 +518,9 @@ int launch_halo_p(const ConvArgs& a, hipStream_t s) {
 
 // single chunk from one source, one column block
 bool halo_persistent(const ConvArgs& a) {
-  static const int on = [] { const char* e = getenv("FLAIR_HALO_PERSIST"); return e ? atoi(e) : 1; }();
-  const int Cin = a.C0 + a.C1;
-  const int want = on == 2 ? 16 : 32;   // 16-channel inputs are purely HBM-bound and do better with more, short-lived workgroups
-  return on && a.C1 == 0 && (Cin == 32 || Cin == want) && a.Cout <= 32;
+  const int on = tune("FLAIR_HALO_PERSIST", 1);   // 2: the 32-channel layers only (round 1 .. mid round 2, when the 16-channel
+  const int Cin = a.C0 + a.C1;                    // layers did better with many short-lived workgroups: prefetch distance 1)
+  return on && a.C1 == 0 && (Cin == 32 || (Cin == 16 && on != 2)) && a.Cout <= 32;
 }
 
 template <typename T, int CK, int BN>
