@@ -277,7 +277,7 @@ static void wg_plan(int dtype, const WgradArgs& a, int& bmk, int& bnn, int& spli
 }
 
 bool wgrad_halo_applicable(const WgradArgs& a);          // wgrad_halo.hip
-size_t wgrad_halo_workspace_bytes(const WgradArgs& a);
+size_t wgrad_halo_workspace_bytes(int dtype, const WgradArgs& a);
 int launch_wgrad_halo(int dtype, const WgradArgs& a, hipStream_t s);
 bool wgrad_stem_applicable(int dtype, const WgradArgs& a);  // stem.hip
 size_t wgrad_stem_workspace_bytes(const WgradArgs& a);
@@ -298,10 +298,10 @@ void launch_wgrad_reduce(const float* partial, float* dw, int splits, int Cout, 
 
 size_t wgrad_workspace_bytes(int dtype, const WgradArgs& a) {
   if (a.in_scale && wgrad_big_applicable(dtype, a)) return wgrad_big_workspace_bytes(dtype, a);
-  if (a.in_scale && wgrad_halo_applicable(a)) return wgrad_halo_workspace_bytes(a);
+  if (a.in_scale && wgrad_halo_applicable(a)) return wgrad_halo_workspace_bytes(dtype, a);
   if (wgrad_stem_applicable(dtype, a)) return wgrad_stem_workspace_bytes(a);
   if (wgrad_big_applicable(dtype, a)) return wgrad_big_workspace_bytes(dtype, a);
-  if (wgrad_halo_applicable(a)) return wgrad_halo_workspace_bytes(a);
+  if (wgrad_halo_applicable(a)) return wgrad_halo_workspace_bytes(dtype, a);
   int bmk, bnn, splits, Kg, Kpad, Cout_pad;
   long pps;
   wg_plan(dtype, a, bmk, bnn, splits, pps, Kg, Kpad, Cout_pad);

@@ -9,6 +9,7 @@
 // written as one fp32 slab per workgroup; wgrad_reduce_kernel (wgrad.hip) sums the slabs in a fixed order.
 #include "common.h"
 #include "prof.h"
+#include "tune.h"
 
 namespace flair {
 
@@ -131,9 +132,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
   // The next tile's X halo and dY tile ride in registers while the current tile is multiplied (round 1 issued the loads
   // of a tile, waited for them and only then computed: with ~3 workgroups per CU the HBM latency of every tile was
   // exposed — 330 us for 300 MB, a fifth of the HBM rate).
-  u32x4 xr[Cfg::XITEMS], dr[Cfg::DITEMS];
-  unsigned xbits = 0, dbits = 0;
-  auto load_tile = [&](int tile) {
+  // (round 2b: two register slots, the loads of tile i + 2 are in flight while tile i is multiplied — the MFMA phase of a tile
+  // is a fraction of an HBM round trip, so distance 1 still waited for every tile)
+  u32x4 xrA[Cfg::XITEMS], drA[Cfg::DITEMS], xrB[Cfg::XITEMS], drB[Cfg::DITEMS];
+  unsigned xbitsA = 0, dbitsA = 0, xbitsB = 0, dbitsB = 0;
+  auto load_tile = [&](int tile, u32x4 (&xr)[Cfg::XITEMS], u32x4 (&dr)[Cfg::DITEMS], unsigned& xbits, unsigned& dbits) {
     const bool tok = tile < a.ntiles;
     const int tl = tok ? tile : 0;
     const int n = tl / (tiles_x * tiles_y);
@@ -164,8 +167,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
     }
     xbits = xb2; dbits = db2;
   };
-  load_tile(blockIdx.x);
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  load_tile(blockIdx.x, xrA, drA, xbitsA, dbitsA);
+  load_tile(blockIdx.x + gridDim.x, xrB, drB, xbitsB, dbitsB);
+  auto do_tile = [&](int tile, u32x4 (&xr)[Cfg::XITEMS], u32x4 (&dr)[Cfg::DITEMS], unsigned& xbits, unsigned& dbits) {
     __syncthreads();  // the previous tile's fragment reads are done
 #pragma unroll
     for (int k = 0; k < Cfg::XITEMS; ++k) {
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
         *reinterpret_cast<u32x4*>(dyt + px * Cfg::DSTRIDE + ch * 16) = dr[k] & (0u - ((dbits >> k) & 1u));
       }
     }
-    load_tile(tile + gridDim.x);
+    load_tile(tile + 2 * gridDim.x, xr, dr, xbits, dbits);   // the slot just staged is free
     __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMA phase (hipcc would sink it to its use)
     __syncthreads();
     // ---- this wave's tile rows (K = ROWS x 32 pixels) of its 16x16 gradient block, all nine taps
@@ -202,6 +206,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
         }
       }
     }
+  };
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += 2 * gridDim.x) {
+    do_tile(tile, xrA, drA, xbitsA, dbitsA);
+    if (tile + gridDim.x < a.ntiles) do_tile(tile + gridDim.x, xrB, drB, xbitsB, dbitsB);
   }
 
   // ---- merge the K parts (fixed order kp 0 <- 1, 2, 3), then one slab per workgroup
@@ -258,6 +266,32 @@ int launch_wg_halo_l(const WgHaloArgs& a, int nsplit, hipStream_t s) {
   return 0;
 }
 
+// resident workgroups per CU of a variant (registers and LDS), asked from the runtime once; 3 without a device
+template <typename T, int CK, int CO, bool LZ>
+int wg_halo_per_cu() {
+  static const int per_cu = [] {
+    int nb = 0;
+    auto kern = wgrad3x3_halo_kernel<T, CK, CO, LZ>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WgHaloCfg<T, CK, CO>::SMEM) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, WgHaloCfg<T, CK, CO>::SMEM) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      return 3;
+    }
+    return nb > 4 ? 4 : nb;
+  }();
+  return per_cu;
+}
+
+template <typename T>
+int wg_halo_per_cu_t(int CK, int CO, bool lz) {
+  if (CK == 16) {
+    if (CO == 16) return lz ? wg_halo_per_cu<T, 16, 16, true>() : wg_halo_per_cu<T, 16, 16, false>();
+    return lz ? wg_halo_per_cu<T, 16, 32, true>() : wg_halo_per_cu<T, 16, 32, false>();
+  }
+  if (CO == 16) return lz ? wg_halo_per_cu<T, 32, 16, true>() : wg_halo_per_cu<T, 32, 16, false>();
+  return lz ? wg_halo_per_cu<T, 32, 32, true>() : wg_halo_per_cu<T, 32, 32, false>();
+}
+
 template <typename T, int CK, int CO>
 int launch_wg_halo(const WgHaloArgs& a, int nsplit, hipStream_t s) {
   return a.in_scale ? launch_wg_halo_l<T, CK, CO, true>(a, nsplit, s) : launch_wg_halo_l<T, CK, CO, false>(a, nsplit, s);
@@ -265,7 +299,8 @@ int launch_wg_halo(const WgHaloArgs& a, int nsplit, hipStream_t s) {
 
 }  // namespace
 
-static bool wg_halo_geom(const WgradArgs& a, int& CK, int& CO, int& nsplit, int& Cout_pad) {
+// dtype < 0: applicability only (nsplit is not computed)
+static bool wg_halo_geom(int dtype, const WgradArgs& a, int& CK, int& CO, int& nsplit, int& Cout_pad) {
   const int Cin = a.C0 + a.C1;
   if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1) return false;
   if (a.Hout != a.Hin || a.Wout != a.Win || (a.Hin % TH) || (a.Win % TW)) return false;
@@ -277,7 +312,12 @@ static bool wg_halo_geom(const WgradArgs& a, int& CK, int& CO, int& nsplit, int&
   CO = Cout_pad % 32 == 0 ? 32 : 16;
   const long ntiles = (long)a.N * a.Hin * a.Win / (TH * TW);
   const int per = (Cin / CK) * (Cout_pad / CO);
-  long ns = 768 / per;           // ~3 resident workgroups per CU in total
+  nsplit = 1;
+  if (dtype < 0) return true;
+  // persistent grid = the workgroups resident at once (a surplus would run as a second, unbalanced round)
+  int wgs = tune("FLAIR_WGH_WGS", 0);
+  if (wgs <= 0) wgs = 256 * (dtype == DT_F32 ? wg_halo_per_cu_t<float>(CK, CO, a.in_scale != nullptr) : wg_halo_per_cu_t<bf16_t>(CK, CO, a.in_scale != nullptr));
+  long ns = wgs / per;
   if (ns > ntiles) ns = ntiles;
   if (ns < 1) ns = 1;
   nsplit = (int)ns;
@@ -286,18 +326,18 @@ static bool wg_halo_geom(const WgradArgs& a, int& CK, int& CO, int& nsplit, int&
 
 bool wgrad_halo_applicable(const WgradArgs& a) {
   int CK, CO, ns, cp;
-  return wg_halo_geom(a, CK, CO, ns, cp);
+  return wg_halo_geom(-1, a, CK, CO, ns, cp);
 }
 
-size_t wgrad_halo_workspace_bytes(const WgradArgs& a) {
+size_t wgrad_halo_workspace_bytes(int dtype, const WgradArgs& a) {
   int CK, CO, ns, cp;
-  if (!wg_halo_geom(a, CK, CO, ns, cp)) return 0;
+  if (!wg_halo_geom(dtype, a, CK, CO, ns, cp)) return 0;
   return (size_t)ns * cp * 9 * (a.C0 + a.C1) * sizeof(float);
 }
 
 int launch_wgrad_halo(int dtype, const WgradArgs& a, hipStream_t s) {
   int CK, CO, nsplit, Cout_pad;
-  if (!wg_halo_geom(a, CK, CO, nsplit, Cout_pad)) return -2;
+  if (!wg_halo_geom(dtype, a, CK, CO, nsplit, Cout_pad)) return -2;
   const int Cin = a.C0 + a.C1;
   WgHaloArgs h;
   h.x0 = a.x0; h.x1 = a.x1; h.C0 = a.C0; h.C1 = a.C1; h.up0 = a.up0; h.N = a.N; h.H = a.Hin; h.W = a.Win;

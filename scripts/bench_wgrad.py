@@ -25,6 +25,10 @@ SHAPES = [("l3 256->256 @32", 32, 256, 256, 11), ("l4 512->512 @16", 16, 512, 51
           ("l1 64->64 @128", 128, 64, 64, 6), ("d0.c2 256->256 @32", 32, 256, 256, 1), ("d1.c2 128->128 @64", 64, 128, 128, 1)]
 
 
+if os.environ.get("SHAPES"):   # "H,Cin,Cout;H,Cin,Cout" (e.g. the small-channel layers: 512,16,16;256,32,32;256,128,32)
+    SHAPES = [(f"{c}->{k} @{h}", h, c, k, 1) for h, c, k in (map(int, t.split(",")) for t in os.environ["SHAPES"].split(";"))]
+
+
 def kernel_ms(prefix):
     n = L.lib().flair_profile_stop()
     name = C.create_string_buffer(96)
@@ -60,7 +64,7 @@ for name, H, Cin, Cout, cnt in SHAPES:
                     d = (dw - ref).abs().max().item()
                     print(f"  mode {m} vs mode {modes[0]} on {name}: max|d|={d:.3g} (scale {ref.abs().max().item():.3g})", flush=True)
             else:
-                times[m].append(sum(v for k, v in t.items() if k.startswith("wgrad3x3_big")))
+                times[m].append(sum(v for k, v in t.items() if k.startswith("wgrad3x3")))
                 red[m].append(t.get("wgrad_reduce", 0.0))
     line = f"{name:22s} {gf:7.1f} GF |"
     for m in modes:
