@@ -516,6 +516,243 @@ int launch_halo_p(const ConvArgs& a, hipStream_t s) {
   return a.in_scale ? launch_halo_p_l<T, CK, BN, true>(a, s) : launch_halo_p_l<T, CK, BN, false>(a, s);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent variant with SEVERAL column blocks per workgroup (32 -> 128 at 256^2: the data gradient of decoder block 3's
+// first convolution, the slowest launch of the step when four 32-wide column blocks each staged the same halo: 373 us for
+// 671 MB).  The weights of all NB blocks stay in LDS (NB x 19 KB), a tile's halo is staged once and multiplied NB times,
+// the C tile is double-buffered so that a block costs one barrier; one workgroup per CU (LDS), prefetch distance 2.
+template <typename T, int CK, int BN, int NB>
+struct HaloPMCfg {
+  using B = HaloCfg<T, CK, BN>;
+  static constexpr int WOFF = 0, HOFF = (NB * B::WBYTES + 255) / 256 * 256, COFF = HOFF + (B::HALO + 255) / 256 * 256;
+  static constexpr int CTB = (B::CT + 255) / 256 * 256;
+  static constexpr int SOFF = COFF + 2 * CTB;
+  static constexpr int SMEM = SOFF + NB * B::STATS;
+};
+
+template <typename T, int CK, int BN, int NB, bool LZ>
+__global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, int ntiles) {
+  using Cfg = HaloCfg<T, CK, BN>;
+  using PC = HaloPMCfg<T, CK, BN, NB>;
+  constexpr int CH = Cfg::CH, KF = Cfg::KF, CPP = Cfg::CPP, TN = BN / 16, TM = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem + PC::WOFF;
+  unsigned char* halo = smem + PC::HOFF;
+  float* st = reinterpret_cast<float*>(smem + PC::SOFF);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int H = a.Hout, W = a.Wout;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  const T* __restrict__ src0 = (const T*)a.src0;
+  const T* __restrict__ wp = (const T*)a.w;
+  const int Hs = a.up0 ? (H >> 1) : H, Ws = a.up0 ? (W >> 1) : W;
+  const int sh = a.up0 ? 1 : 0;
+
+  if constexpr (Cfg::KW > 9 * CK) {
+    constexpr int PADC = (Cfg::KW - 9 * CK) / CH;
+    for (int it = t; it < NB * BN * PADC; it += 256) {
+      const int row = it / PADC, pc = it - row * PADC;
+      *reinterpret_cast<u32x4*>(wl + row * Cfg::WROW + (9 * CK + pc * CH) * (int)sizeof(T)) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  for (int it = t; it < NB * BN * 9 * CPP; it += 256) {
+    const int row = it / (9 * CPP), rem = it - row * (9 * CPP);
+    const int tap = rem / CPP, ch = rem - tap * CPP;
+    *reinterpret_cast<u32x4*>(wl + row * Cfg::WROW + rem * 16) =
+        *reinterpret_cast<const u32x4*>(wp + (long)row * a.Kpad + tap * CK + ch * CH);
+  }
+  float lsc[CH], lsh[CH];
+  if (LZ && a.in_scale) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      lsc[e] = a.in_scale[(t % CPP) * CH + e];
+      lsh[e] = a.in_shift[(t % CPP) * CH + e];
+    }
+  }
+  float osc[NB][TN], obi[NB][TN], s1[NB][TN], s2[NB][TN];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < TN; ++q) {
+      const int col = nb * BN + q * 16 + lr;
+      const bool cok = col < a.Cout;
+      osc[nb][q] = (a.oscale && cok) ? a.oscale[col] : 1.f;
+      obi[nb][q] = ((a.bias && cok) ? a.bias[col] : 0.f) + ((a.oshift && cok) ? a.oshift[col] : 0.f);
+      s1[nb][q] = 0.f; s2[nb][q] = 0.f;
+    }
+
+  u32x4 hregA[Cfg::HITEMS], hregB[Cfg::HITEMS];
+  unsigned hbitsA = 0, hbitsB = 0;
+  auto halo_load = [&](int tile, u32x4 (&hreg)[Cfg::HITEMS], unsigned& hbits) {
+    const bool tok = tile < ntiles;
+    const int tl = tok ? tile : 0;
+    const int n = tl / (tiles_x * tiles_y);
+    const int trem = tl - n * tiles_x * tiles_y;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    unsigned hb = 0;
+#pragma unroll
+    for (int k = 0; k < Cfg::HITEMS; ++k) {
+      const int it = t + 256 * k;
+      const int hp = it / CPP, ch = it - hp * CPP;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = tok && (it < HPIX * CPP) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+      const unsigned off = ok ? (unsigned)(((n * Hs + (iy >> sh)) * Ws + (ix >> sh)) * CK + ch * CH) : 0u;
+      hreg[k] = *reinterpret_cast<const u32x4*>(src0 + off);
+      hb |= (ok ? 1u : 0u) << k;
+    }
+    hbits = hb;
+  };
+  auto halo_store = [&](const u32x4 (&hreg)[Cfg::HITEMS], unsigned hbits) {
+#pragma unroll
+    for (int k = 0; k < Cfg::HITEMS; ++k) {
+      const int it = t + 256 * k;
+      if (it < HPIX * CPP) {
+        const int hp = it / CPP, ch = it - hp * CPP;
+        const u32x4 hv = (LZ && a.in_scale) ? chunk_bn_relu<T>(hreg[k], lsc, lsh) : hreg[k];
+        *reinterpret_cast<u32x4*>(halo + hp * Cfg::PSTRIDE + ch * 16) = hv & (0u - ((hbits >> k) & 1u));
+      }
+    }
+  };
+
+  halo_load(blockIdx.x, hregA, hbitsA);
+  halo_load(blockIdx.x + gridDim.x, hregB, hbitsB);
+  halo_store(hregA, hbitsA);
+  __syncthreads();
+  auto do_tile = [&](int tile, u32x4 (&ld)[Cfg::HITEMS], unsigned& ldbits, const u32x4 (&stg)[Cfg::HITEMS], const unsigned& stbits) {
+    halo_load(tile + 2 * gridDim.x, ld, ldbits);
+    __builtin_amdgcn_sched_barrier(0);
+    const int n = tile / (tiles_x * tiles_y);
+    const int trem = tile - n * tiles_x * tiles_y;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      unsigned char* ct = smem + PC::COFF + (nb & 1) * PC::CTB;
+      f32x4_t acc[TM][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < Cfg::KW / KF; ++j) {
+        const int k0 = j * KF + lq * CH;
+        int tap = k0 / CK;
+        const int c = k0 - tap * CK;
+        tap = tap > 8 ? 8 : tap;
+        const int r = tap / 3, s = tap - 3 * r;
+        u32x4 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int py = 2 * wave + (i >> 1), px = (i & 1) * 16 + lr;
+          af[i] = *reinterpret_cast<const u32x4*>(halo + ((py + r) * HW_ + px + s) * Cfg::PSTRIDE + c * (int)sizeof(T));
+        }
+#pragma unroll
+        for (int q = 0; q < TN; ++q)
+          bfr[q] = *reinterpret_cast<const u32x4*>(wl + (nb * BN + q * 16 + lr) * Cfg::WROW + k0 * (int)sizeof(T));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < TN; ++q) HMma<T>::run(af[i], bfr[q], acc[i][q]);
+      }
+#pragma unroll
+      for (int q = 0; q < TN; ++q) {
+        const int col = q * 16 + lr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int row = (2 * wave + (i >> 1)) * TW + (i & 1) * 16 + lq * 4 + rr;
+            const T v = Elem<T>::from_f(fmaf(acc[i][q][rr], osc[nb][q], obi[nb][q]));
+            const float vf = Elem<T>::to_f(v);
+            s1[nb][q] += vf;
+            s2[nb][q] = fmaf(vf, vf, s2[nb][q]);
+            *reinterpret_cast<T*>(ct + row * Cfg::CLD + col * (int)sizeof(T)) = v;
+          }
+        }
+      }
+      __syncthreads();   // this block's C tile is complete (last block: every wave is done with the halo too)
+      if (nb == NB - 1) halo_store(stg, stbits);
+      store_tile<T, TW, TH * TW, BN, 256, Cfg::CLD>(a, ct, n, y0, x0, nb * BN, t);
+    }
+    __syncthreads();   // next halo visible
+  };
+  for (int tile = blockIdx.x; tile < ntiles; tile += 2 * gridDim.x) {
+    do_tile(tile, hregA, hbitsA, hregB, hbitsB);
+    if (tile + gridDim.x < ntiles) do_tile(tile + gridDim.x, hregB, hbitsB, hregA, hbitsA);
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int q = 0; q < TN; ++q) {
+        float x1 = s1[nb][q], x2 = s2[nb][q];
+        x1 += __shfl_xor(x1, 16); x1 += __shfl_xor(x1, 32);
+        x2 += __shfl_xor(x2, 16); x2 += __shfl_xor(x2, 32);
+        if (lq == 0) {
+          st[(wave * NB * BN + nb * BN + q * 16 + lr) * 2 + 0] = x1;
+          st[(wave * NB * BN + nb * BN + q * 16 + lr) * 2 + 1] = x2;
+        }
+      }
+    __syncthreads();
+    if (t < NB * BN && t < a.Cout) {
+      float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { x1 += st[(w * NB * BN + t) * 2]; x2 += st[(w * NB * BN + t) * 2 + 1]; }
+      a.stats[(long)t * gridDim.x + blockIdx.x] = x1;
+      a.stats[((long)a.Cout + t) * gridDim.x + blockIdx.x] = x2;
+    }
+  }
+}
+
+template <typename T, int CK, int BN, int NB, bool LZ>
+int halo_pm_per_cu() {
+  static const int per_cu = [] {
+    int nb = 0;
+    auto kern = conv3x3_halo_pm_kernel<T, CK, BN, NB, LZ>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HaloPMCfg<T, CK, BN, NB>::SMEM) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, HaloPMCfg<T, CK, BN, NB>::SMEM) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      return 1;
+    }
+    return nb > 4 ? 4 : nb;
+  }();
+  return per_cu;
+}
+
+template <typename T, int CK, int BN, int NB>
+int halo_pm_blocks(const ConvArgs& a) {
+  const long ntiles = (long)a.N * a.Hout * a.Wout / (TH * TW);
+  const long cap = 256L * (a.in_scale ? halo_pm_per_cu<T, CK, BN, NB, true>() : halo_pm_per_cu<T, CK, BN, NB, false>());
+  return (int)(ntiles < cap ? ntiles : cap);
+}
+
+template <typename T, int CK, int BN, int NB, bool LZ>
+int launch_halo_pm_l(const ConvArgs& a, hipStream_t s) {
+  using PC = HaloPMCfg<T, CK, BN, NB>;
+  auto kern = conv3x3_halo_pm_kernel<T, CK, BN, NB, LZ>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long M = (long)a.N * a.Hout * a.Wout;
+  {
+    const double flops = 2.0 * (double)M * a.Cout * a.Kg;
+    const double bytes = ((double)M / (a.up0 ? 4 : 1) * a.C0 + (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) + (double)a.Cout * a.Kg * sizeof(T);
+    ProfScope ps(CK == 32 ? "conv3x3_halo_bf16_ck32" : "conv3x3_halo_bf16_ck16", flops, bytes, s);
+    hipLaunchKernelGGL(kern, dim3(halo_pm_blocks<T, CK, BN, NB>(a)), dim3(256), PC::SMEM, s, a, (int)(M / (TH * TW)));
+  }
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+// bf16, 32 input channels from one source, 128 output channels (four 32-wide blocks), no fp32 NCHW copy
+bool halo_persistent_multi(int dtype, const ConvArgs& a) {
+  return dtype != DT_F32 && tune("FLAIR_HALO_PM", 1) && a.C1 == 0 && a.C0 == 32 && a.Cout == 128 && !a.out_nchw && (a.pool_c0 % 32) == 0;
+}
+
 // single chunk from one source, one column block
 bool halo_persistent(const ConvArgs& a) {
   const int on = tune("FLAIR_HALO_PERSIST", 1);   // 2: the 32-channel layers only (round 1 .. mid round 2, when the 16-channel
@@ -550,6 +787,7 @@ static int halo_rows_t(const ConvArgs& a) {
 }
 
 int conv_halo_grid_rows(int dtype, const ConvArgs& a) {
+  if (halo_persistent_multi(dtype, a)) return halo_pm_blocks<bf16_t, 32, 32, 4>(a);
   if (halo_persistent(a)) return dtype == DT_F32 ? halo_rows_t<float>(a) : halo_rows_t<bf16_t>(a);
   return (int)((long)a.N * a.Hout * a.Wout / (TH * TW));
 }
@@ -557,6 +795,8 @@ int conv_halo_grid_rows(int dtype, const ConvArgs& a) {
 int launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s) {
   const int Cin = a.C0 + a.C1;
   const bool n16 = a.Cout <= 16;
+  if (halo_persistent_multi(dtype, a))
+    return a.in_scale ? launch_halo_pm_l<bf16_t, 32, 32, 4, true>(a, s) : launch_halo_pm_l<bf16_t, 32, 32, 4, false>(a, s);
   if (halo_persistent(a)) {
     if (dtype == DT_F32) {
       if (Cin == 16) return n16 ? launch_halo_p<float, 16, 16>(a, s) : launch_halo_p<float, 16, 32>(a, s);
