@@ -10,6 +10,7 @@
 #include "common.h"
 #include "prof.h"
 #include "tile_store.h"
+#include "tile_direct.h"
 #include "tune.h"
 
 namespace flair {
@@ -273,9 +274,8 @@ int launch_halo_cfg_l(const ConvArgs& a, hipStream_t s) {
 template <typename T, int CK, int BN>
 struct HaloPCfg {
   using B = HaloCfg<T, CK, BN>;
-  static constexpr int WOFF = 0, HOFF = (B::WBYTES + 255) / 256 * 256, COFF = HOFF + (B::HALO + 255) / 256 * 256;
-  static constexpr int SOFF = COFF + (B::CT + 255) / 256 * 256;
-  static constexpr int SMEM = SOFF + B::STATS;
+  static constexpr int WOFF = 0, HOFF = (B::WBYTES + 255) / 256 * 256, SOFF = HOFF + (B::HALO + 255) / 256 * 256;
+  static constexpr int SMEM = SOFF + B::STATS;   // no C tile: the epilogue goes from registers to HBM (tile_direct.h)
 };
 
 template <typename T, int CK, int BN, bool LZ>
@@ -286,7 +286,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* wl = smem + PC::WOFF;
   unsigned char* halo = smem + PC::HOFF;
-  unsigned char* ct = smem + PC::COFF;
   float* st = reinterpret_cast<float*>(smem + PC::SOFF);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
@@ -319,15 +318,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
       lsh[e] = a.in_shift[(t % CPP) * CH + e];
     }
   }
-  float osc[TN], obi[TN], s1[TN], s2[TN];
+  DirectCoef<TN> cf;
+  cf.load(a, 0, lq);
+  float s1[4 * TN], s2[4 * TN];
 #pragma unroll
-  for (int q = 0; q < TN; ++q) {
-    const int col = q * 16 + lr;
-    const bool cok = col < a.Cout;
-    osc[q] = (a.oscale && cok) ? a.oscale[col] : 1.f;
-    obi[q] = ((a.bias && cok) ? a.bias[col] : 0.f) + ((a.oshift && cok) ? a.oshift[col] : 0.f);
-    s1[q] = 0.f; s2[q] = 0.f;
-  }
+  for (int e = 0; e < 4 * TN; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 
   // Two register slots: the halo of tile i + 2 is requested while tile i is multiplied (the MFMA phase of a 16-32-channel tile
   // is ~0.3 us, an HBM round trip under load ~2 us: with one slot every iteration waited for its loads)
@@ -369,7 +364,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
   halo_load(blockIdx.x + gridDim.x, hregB, hbitsB);
   halo_store(hregA, hbitsA);
   __syncthreads();
-  // one tile: request tile + 2 strides into the slot that is free (`ld`), multiply, stage the next tile from the other (`st`)
+  // one tile: request tile + 2 strides into the slot that is free (`ld`), multiply, store from registers, stage the next
+  // tile from the other slot (`stg`)
   auto do_tile = [&](int tile, u32x4 (&ld)[Cfg::HITEMS], unsigned& ldbits, const u32x4 (&stg)[Cfg::HITEMS], const unsigned& stbits) {
     halo_load(tile + 2 * gridDim.x, ld, ldbits);
     __builtin_amdgcn_sched_barrier(0);
@@ -393,62 +389,28 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
       }
 #pragma unroll
       for (int q = 0; q < TN; ++q)
-        bfr[q] = *reinterpret_cast<const u32x4*>(wl + (q * 16 + lr) * Cfg::WROW + k0 * (int)sizeof(T));
+        bfr[q] = *reinterpret_cast<const u32x4*>(wl + direct_row_channel<TN>(q, lr) * Cfg::WROW + k0 * (int)sizeof(T));
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < TN; ++q) HMma<T>::run(af[i], bfr[q], acc[i][q]);
+        for (int q = 0; q < TN; ++q) HMma<T>::run(bfr[q], af[i], acc[i][q]);   // weights as A: D = [cout][pixel]
     }
-#pragma unroll
-    for (int q = 0; q < TN; ++q) {
-      const int col = q * 16 + lr;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int row = (2 * wave + (i >> 1)) * TW + (i & 1) * 16 + lq * 4 + rr;  // tile-local pixel
-          const T v = Elem<T>::from_f(fmaf(acc[i][q][rr], osc[q], obi[q]));
-          const float vf = Elem<T>::to_f(v);
-          s1[q] += vf;
-          s2[q] = fmaf(vf, vf, s2[q]);
-          *reinterpret_cast<T*>(ct + row * Cfg::CLD + col * (int)sizeof(T)) = v;
-        }
-      }
-    }
-    __syncthreads();   // every wave is done with the halo, the C tile is complete
-    halo_store(stg, stbits);
     {
       const int n = tile / (tiles_x * tiles_y);
       const int trem = tile - n * tiles_x * tiles_y;
       const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
-      store_tile<T, TW, TH * TW, BN, 256, Cfg::CLD>(a, ct, n, y0, x0, 0, t);
-      if (a.out_nchw) {
-        const long HWp = (long)H * W;
-        for (int idx = t; idx < TH * TW * BN; idx += 256) {
-          const int nl = idx / (TH * TW), ml = idx - nl * (TH * TW);
-          const int py = ml / TW, px = ml - py * TW;
-          if (nl < a.Cout)
-            a.out_nchw[((long)n * a.Cout + nl) * HWp + (long)(y0 + py) * W + x0 + px] =
-                Elem<T>::to_f(*reinterpret_cast<const T*>(ct + ml * Cfg::CLD + nl * (int)sizeof(T)));
-        }
-      }
+      direct_store<T, TW, TN>(a, acc, n, y0, x0, 0, wave, lane, cf, s1, s2);
     }
-    __syncthreads();   // next halo visible, C tile free
+    __syncthreads();   // every wave is done with the halo
+    halo_store(stg, stbits);
+    __syncthreads();   // next halo visible
   };
   for (int tile = blockIdx.x; tile < ntiles; tile += 2 * gridDim.x) {
     do_tile(tile, hregA, hbitsA, hregB, hbitsB);   // slot A went to LDS before this tile; B holds the next one
     if (tile + gridDim.x < ntiles) do_tile(tile + gridDim.x, hregB, hbitsB, hregA, hbitsA);
   }
   if (a.stats) {
-#pragma unroll
-    for (int q = 0; q < TN; ++q) {
-      s1[q] += __shfl_xor(s1[q], 16); s1[q] += __shfl_xor(s1[q], 32);
-      s2[q] += __shfl_xor(s2[q], 16); s2[q] += __shfl_xor(s2[q], 32);
-      if (lq == 0) {
-        st[(wave * BN + q * 16 + lr) * 2 + 0] = s1[q];
-        st[(wave * BN + q * 16 + lr) * 2 + 1] = s2[q];
-      }
-    }
+    direct_stats_wave<TN>(s1, s2, st, BN, 0, wave, lane);
     __syncthreads();
     if (t < BN && t < a.Cout) {
       float x1 = 0.f, x2 = 0.f;
@@ -521,13 +483,12 @@ int launch_halo_p(const ConvArgs& a, hipStream_t s) {
 // Persistent variant with SEVERAL column blocks per workgroup (32 -> 128 at 256^2: the data gradient of decoder block 3's
 // first convolution, the slowest launch of the step when four 32-wide column blocks each staged the same halo: 373 us for
 // 671 MB).  The weights of all NB blocks stay in LDS (NB x 19 KB), a tile's halo is staged once and multiplied NB times,
-// the C tile is double-buffered so that a block costs one barrier; one workgroup per CU (LDS), prefetch distance 2.
+// every block's result goes from registers to HBM (tile_direct.h): two barriers per TILE; one workgroup per CU (LDS),
+// prefetch distance 2.
 template <typename T, int CK, int BN, int NB>
 struct HaloPMCfg {
   using B = HaloCfg<T, CK, BN>;
-  static constexpr int WOFF = 0, HOFF = (NB * B::WBYTES + 255) / 256 * 256, COFF = HOFF + (B::HALO + 255) / 256 * 256;
-  static constexpr int CTB = (B::CT + 255) / 256 * 256;
-  static constexpr int SOFF = COFF + 2 * CTB;
+  static constexpr int WOFF = 0, HOFF = (NB * B::WBYTES + 255) / 256 * 256, SOFF = HOFF + (B::HALO + 255) / 256 * 256;
   static constexpr int SMEM = SOFF + NB * B::STATS;
 };
 
@@ -570,17 +531,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
       lsh[e] = a.in_shift[(t % CPP) * CH + e];
     }
   }
-  float osc[NB][TN], obi[NB][TN], s1[NB][TN], s2[NB][TN];
+  DirectCoef<TN> cf[NB];
+  float s1[NB][4 * TN], s2[NB][4 * TN];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
+  for (int nb = 0; nb < NB; ++nb) {
+    cf[nb].load(a, nb * BN, lq);
 #pragma unroll
-    for (int q = 0; q < TN; ++q) {
-      const int col = nb * BN + q * 16 + lr;
-      const bool cok = col < a.Cout;
-      osc[nb][q] = (a.oscale && cok) ? a.oscale[col] : 1.f;
-      obi[nb][q] = ((a.bias && cok) ? a.bias[col] : 0.f) + ((a.oshift && cok) ? a.oshift[col] : 0.f);
-      s1[nb][q] = 0.f; s2[nb][q] = 0.f;
-    }
+    for (int e = 0; e < 4 * TN; ++e) { s1[nb][e] = 0.f; s2[nb][e] = 0.f; }
+  }
 
   u32x4 hregA[Cfg::HITEMS], hregB[Cfg::HITEMS];
   unsigned hbitsA = 0, hbitsB = 0;
@@ -628,7 +586,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      unsigned char* ct = smem + PC::COFF + (nb & 1) * PC::CTB;
       f32x4_t acc[TM][TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -649,32 +606,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
         }
 #pragma unroll
         for (int q = 0; q < TN; ++q)
-          bfr[q] = *reinterpret_cast<const u32x4*>(wl + (nb * BN + q * 16 + lr) * Cfg::WROW + k0 * (int)sizeof(T));
+          bfr[q] = *reinterpret_cast<const u32x4*>(wl + (nb * BN + direct_row_channel<TN>(q, lr)) * Cfg::WROW + k0 * (int)sizeof(T));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int q = 0; q < TN; ++q) HMma<T>::run(af[i], bfr[q], acc[i][q]);
+          for (int q = 0; q < TN; ++q) HMma<T>::run(bfr[q], af[i], acc[i][q]);
       }
-#pragma unroll
-      for (int q = 0; q < TN; ++q) {
-        const int col = q * 16 + lr;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int row = (2 * wave + (i >> 1)) * TW + (i & 1) * 16 + lq * 4 + rr;
-            const T v = Elem<T>::from_f(fmaf(acc[i][q][rr], osc[nb][q], obi[nb][q]));
-            const float vf = Elem<T>::to_f(v);
-            s1[nb][q] += vf;
-            s2[nb][q] = fmaf(vf, vf, s2[nb][q]);
-            *reinterpret_cast<T*>(ct + row * Cfg::CLD + col * (int)sizeof(T)) = v;
-          }
-        }
-      }
-      __syncthreads();   // this block's C tile is complete (last block: every wave is done with the halo too)
-      if (nb == NB - 1) halo_store(stg, stbits);
-      store_tile<T, TW, TH * TW, BN, 256, Cfg::CLD>(a, ct, n, y0, x0, nb * BN, t);
+      direct_store<T, TW, TN>(a, acc, n, y0, x0, nb * BN, wave, lane, cf[nb], s1[nb], s2[nb]);   // registers -> HBM, no barrier
     }
+    __syncthreads();   // every wave is done with the halo
+    halo_store(stg, stbits);
     __syncthreads();   // next halo visible
   };
   for (int tile = blockIdx.x; tile < ntiles; tile += 2 * gridDim.x) {
@@ -683,17 +624,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
   }
   if (a.stats) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int q = 0; q < TN; ++q) {
-        float x1 = s1[nb][q], x2 = s2[nb][q];
-        x1 += __shfl_xor(x1, 16); x1 += __shfl_xor(x1, 32);
-        x2 += __shfl_xor(x2, 16); x2 += __shfl_xor(x2, 32);
-        if (lq == 0) {
-          st[(wave * NB * BN + nb * BN + q * 16 + lr) * 2 + 0] = x1;
-          st[(wave * NB * BN + nb * BN + q * 16 + lr) * 2 + 1] = x2;
-        }
-      }
+    for (int nb = 0; nb < NB; ++nb) direct_stats_wave<TN>(s1[nb], s2[nb], st, NB * BN, nb * BN, wave, lane);
     __syncthreads();
     if (t < NB * BN && t < a.Cout) {
       float x1 = 0.f, x2 = 0.f;
