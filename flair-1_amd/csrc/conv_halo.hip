@@ -489,19 +489,22 @@ template <typename T, int CK, int BN, int NB>
 struct HaloPMCfg {
   using B = HaloCfg<T, CK, BN>;
   static constexpr int WOFF = 0, HOFF = (NB * B::WBYTES + 255) / 256 * 256, SOFF = HOFF + (B::HALO + 255) / 256 * 256;
-  static constexpr int SMEM = SOFF + NB * B::STATS;
+  static constexpr int SMEM = SOFF;
 };
 
-template <typename T, int CK, int BN, int NB, bool LZ>
-__global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, int ntiles) {
+// NT = 512: two wave groups share the staged halo, each takes half of the column blocks (two waves per SIMD: with one, every
+// LDS read and conversion of the epilogue sat in the MFMA's shadow-less critical path: 349 us)
+template <typename T, int CK, int BN, int NB, bool LZ, int NT>
+__global__ __launch_bounds__(NT) void conv3x3_halo_pm_kernel(const ConvArgs a, int ntiles) {
   using Cfg = HaloCfg<T, CK, BN>;
   using PC = HaloPMCfg<T, CK, BN, NB>;
   constexpr int CH = Cfg::CH, KF = Cfg::KF, CPP = Cfg::CPP, TN = BN / 16, TM = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* wl = smem + PC::WOFF;
   unsigned char* halo = smem + PC::HOFF;
-  float* st = reinterpret_cast<float*>(smem + PC::SOFF);
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = (t >> 6) & 3, wgrp = t >> 8;
+  constexpr int NG = NT / 256, NBG = NB / NG, HIT = (HPIX * Cfg::CPP + NT - 1) / NT;
+  static_assert(NB % NG == 0, "column blocks per wave group");
   const int lr = lane & 15, lq = lane >> 4;
   const int H = a.Hout, W = a.Wout;
   const int tiles_x = W / TW, tiles_y = H / TH;
@@ -512,12 +515,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
 
   if constexpr (Cfg::KW > 9 * CK) {
     constexpr int PADC = (Cfg::KW - 9 * CK) / CH;
-    for (int it = t; it < NB * BN * PADC; it += 256) {
+    for (int it = t; it < NB * BN * PADC; it += NT) {
       const int row = it / PADC, pc = it - row * PADC;
       *reinterpret_cast<u32x4*>(wl + row * Cfg::WROW + (9 * CK + pc * CH) * (int)sizeof(T)) = u32x4{0u, 0u, 0u, 0u};
     }
   }
-  for (int it = t; it < NB * BN * 9 * CPP; it += 256) {
+  for (int it = t; it < NB * BN * 9 * CPP; it += NT) {
     const int row = it / (9 * CPP), rem = it - row * (9 * CPP);
     const int tap = rem / CPP, ch = rem - tap * CPP;
     *reinterpret_cast<u32x4*>(wl + row * Cfg::WROW + rem * 16) =
@@ -531,18 +534,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
       lsh[e] = a.in_shift[(t % CPP) * CH + e];
     }
   }
-  DirectCoef<TN> cf[NB];
-  float s1[NB][4 * TN], s2[NB][4 * TN];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    cf[nb].load(a, nb * BN, lq);
-#pragma unroll
-    for (int e = 0; e < 4 * TN; ++e) { s1[nb][e] = 0.f; s2[nb][e] = 0.f; }
-  }
+  DirectCoef<TN> cf;              // unused: plain results only (no per-channel affine, no statistics: halo_persistent_multi)
+  float s1[4 * TN], s2[4 * TN];
 
-  u32x4 hregA[Cfg::HITEMS], hregB[Cfg::HITEMS];
+  u32x4 hregA[HIT], hregB[HIT];
   unsigned hbitsA = 0, hbitsB = 0;
-  auto halo_load = [&](int tile, u32x4 (&hreg)[Cfg::HITEMS], unsigned& hbits) {
+  auto halo_load = [&](int tile, u32x4 (&hreg)[HIT], unsigned& hbits) {
     const bool tok = tile < ntiles;
     const int tl = tok ? tile : 0;
     const int n = tl / (tiles_x * tiles_y);
@@ -550,8 +547,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
     unsigned hb = 0;
 #pragma unroll
-    for (int k = 0; k < Cfg::HITEMS; ++k) {
-      const int it = t + 256 * k;
+    for (int k = 0; k < HIT; ++k) {
+      const int it = t + NT * k;
       const int hp = it / CPP, ch = it - hp * CPP;
       const int hy = hp / HW_, hx = hp - hy * HW_;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
@@ -562,10 +559,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
     }
     hbits = hb;
   };
-  auto halo_store = [&](const u32x4 (&hreg)[Cfg::HITEMS], unsigned hbits) {
+  auto halo_store = [&](const u32x4 (&hreg)[HIT], unsigned hbits) {
 #pragma unroll
-    for (int k = 0; k < Cfg::HITEMS; ++k) {
-      const int it = t + 256 * k;
+    for (int k = 0; k < HIT; ++k) {
+      const int it = t + NT * k;
       if (it < HPIX * CPP) {
         const int hp = it / CPP, ch = it - hp * CPP;
         const u32x4 hv = (LZ && a.in_scale) ? chunk_bn_relu<T>(hreg[k], lsc, lsh) : hreg[k];
@@ -578,14 +575,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
   halo_load(blockIdx.x + gridDim.x, hregB, hbitsB);
   halo_store(hregA, hbitsA);
   __syncthreads();
-  auto do_tile = [&](int tile, u32x4 (&ld)[Cfg::HITEMS], unsigned& ldbits, const u32x4 (&stg)[Cfg::HITEMS], const unsigned& stbits) {
+  auto do_tile = [&](int tile, u32x4 (&ld)[HIT], unsigned& ldbits, const u32x4 (&stg)[HIT], const unsigned& stbits) {
     halo_load(tile + 2 * gridDim.x, ld, ldbits);
     __builtin_amdgcn_sched_barrier(0);
     const int n = tile / (tiles_x * tiles_y);
     const int trem = tile - n * tiles_x * tiles_y;
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
+    for (int jb = 0; jb < NBG; ++jb) {
+      const int nb = wgrp * NBG + jb;
       f32x4_t acc[TM][TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -612,7 +610,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
 #pragma unroll
           for (int q = 0; q < TN; ++q) HMma<T>::run(bfr[q], af[i], acc[i][q]);
       }
-      direct_store<T, TW, TN>(a, acc, n, y0, x0, nb * BN, wave, lane, cf[nb], s1[nb], s2[nb]);   // registers -> HBM, no barrier
+      direct_store<T, TW, TN, false>(a, acc, n, y0, x0, nb * BN, wave, lane, cf, s1, s2);   // registers -> HBM, no barrier
     }
     __syncthreads();   // every wave is done with the halo
     halo_store(stg, stbits);
@@ -622,27 +620,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_pm_kernel(const ConvArgs a, 
     do_tile(tile, hregA, hbitsA, hregB, hbitsB);
     if (tile + gridDim.x < ntiles) do_tile(tile + gridDim.x, hregB, hbitsB, hregA, hbitsA);
   }
-  if (a.stats) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) direct_stats_wave<TN>(s1[nb], s2[nb], st, NB * BN, nb * BN, wave, lane);
-    __syncthreads();
-    if (t < NB * BN && t < a.Cout) {
-      float x1 = 0.f, x2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { x1 += st[(w * NB * BN + t) * 2]; x2 += st[(w * NB * BN + t) * 2 + 1]; }
-      a.stats[(long)t * gridDim.x + blockIdx.x] = x1;
-      a.stats[((long)a.Cout + t) * gridDim.x + blockIdx.x] = x2;
-    }
-  }
 }
+
+constexpr int PM_NT = 512;
 
 template <typename T, int CK, int BN, int NB, bool LZ>
 int halo_pm_per_cu() {
   static const int per_cu = [] {
     int nb = 0;
-    auto kern = conv3x3_halo_pm_kernel<T, CK, BN, NB, LZ>;
+    auto kern = conv3x3_halo_pm_kernel<T, CK, BN, NB, LZ, PM_NT>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HaloPMCfg<T, CK, BN, NB>::SMEM) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, HaloPMCfg<T, CK, BN, NB>::SMEM) != hipSuccess || nb < 1) {
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, PM_NT, HaloPMCfg<T, CK, BN, NB>::SMEM) != hipSuccess || nb < 1) {
       (void)hipGetLastError();
       return 1;
     }
@@ -661,7 +649,7 @@ int halo_pm_blocks(const ConvArgs& a) {
 template <typename T, int CK, int BN, int NB, bool LZ>
 int launch_halo_pm_l(const ConvArgs& a, hipStream_t s) {
   using PC = HaloPMCfg<T, CK, BN, NB>;
-  auto kern = conv3x3_halo_pm_kernel<T, CK, BN, NB, LZ>;
+  auto kern = conv3x3_halo_pm_kernel<T, CK, BN, NB, LZ, PM_NT>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM);
@@ -673,7 +661,7 @@ int launch_halo_pm_l(const ConvArgs& a, hipStream_t s) {
     const double flops = 2.0 * (double)M * a.Cout * a.Kg;
     const double bytes = ((double)M / (a.up0 ? 4 : 1) * a.C0 + (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) + (double)a.Cout * a.Kg * sizeof(T);
     ProfScope ps(CK == 32 ? "conv3x3_halo_bf16_ck32" : "conv3x3_halo_bf16_ck16", flops, bytes, s);
-    hipLaunchKernelGGL(kern, dim3(halo_pm_blocks<T, CK, BN, NB>(a)), dim3(256), PC::SMEM, s, a, (int)(M / (TH * TW)));
+    hipLaunchKernelGGL(kern, dim3(halo_pm_blocks<T, CK, BN, NB>(a)), dim3(PM_NT), PC::SMEM, s, a, (int)(M / (TH * TW)));
   }
   FLAIR_CHECK_LAUNCH();
   return 0;
@@ -681,7 +669,8 @@ int launch_halo_pm_l(const ConvArgs& a, hipStream_t s) {
 
 // bf16, 32 input channels from one source, 128 output channels (four 32-wide blocks), no fp32 NCHW copy
 bool halo_persistent_multi(int dtype, const ConvArgs& a) {
-  return dtype != DT_F32 && tune("FLAIR_HALO_PM", 1) && a.C1 == 0 && a.C0 == 32 && a.Cout == 128 && !a.out_nchw && (a.pool_c0 % 32) == 0;
+  return dtype != DT_F32 && tune("FLAIR_HALO_PM", 1) && a.C1 == 0 && a.C0 == 32 && a.Cout == 128 && !a.out_nchw && (a.pool_c0 % 32) == 0 &&
+         !a.stats && !a.oscale && !a.oshift && !a.bias;
 }
 
 // single chunk from one source, one column block

@@ -80,7 +80,8 @@ struct DirectCoef {
 // One 8x32 tile of one column block (16*TN channels from n0): acc[i][q] = block (tile row 2*wave + (i >> 1), pixels
 // (i & 1)*16 .. +15) x (weight rows q*16 .. +15), element [rr] = row 4*lq + rr of pixel lr = channel n0 + 4*TN*lq + q*4 + rr.
 // s1 / s2: running per-lane BatchNorm sums of the ROUNDED outputs (statistics of what the next layer reads).
-template <typename T, int TW_, int TN>
+// AFF = false: no per-channel affine and no statistics (plain data gradients): cf / s1 / s2 are not touched
+template <typename T, int TW_, int TN, bool AFF = true>
 __device__ __forceinline__ void direct_store(const ConvArgs& a, const f32x4_t (&acc)[4][TN], int n, int y0, int x0, int n0, int wave,
                                              int lane, const DirectCoef<TN>& cf, float (&s1)[4 * TN], float (&s2)[4 * TN]) {
   constexpr int CH = Elem<T>::CH, NCH = 4 * TN;
@@ -97,9 +98,13 @@ __device__ __forceinline__ void direct_store(const ConvArgs& a, const f32x4_t (&
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int e = q * 4 + rr;
-        v[i][e] = Elem<T>::to_f(Elem<T>::from_f(fmaf(acc[i][q][rr], cf.osc[e], cf.obi[e])));
-        s1[e] += v[i][e];
-        s2[e] = fmaf(v[i][e], v[i][e], s2[e]);
+        if constexpr (AFF) {
+          v[i][e] = Elem<T>::to_f(Elem<T>::from_f(fmaf(acc[i][q][rr], cf.osc[e], cf.obi[e])));
+          s1[e] += v[i][e];
+          s2[e] = fmaf(v[i][e], v[i][e], s2[e]);
+        } else {
+          v[i][e] = Elem<T>::to_f(Elem<T>::from_f(acc[i][q][rr]));
+        }
       }
   if (a.out_nchw) {
     const long HWp = (long)H * W;
