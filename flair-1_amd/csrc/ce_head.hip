@@ -133,14 +133,15 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const float* __restrict__ 
     float ssum = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
-      if (c < C) { x[c] = expf(x[c] - m); ssum += x[c]; }
+      if (c < C) { x[c] = __expf(x[c] - m); ssum += x[c]; }
     // probabilities, argmax(softmax) with first-index tie break (task_module.py:75-76)
+    const float rs = 1.f / ssum;   // one division per pixel (was one per class; with __expf: 665 -> ~300 vector instructions per pixel)
     int pred = 0;
     float pbest = -1.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
       if (c < C) {
-        x[c] = x[c] / ssum;
+        x[c] = x[c] * rs;
         if (x[c] > pbest) { pbest = x[c]; pred = c; }
       }
     const int y = lab8[i];
@@ -225,13 +226,14 @@ __global__ __launch_bounds__(256) void ce_main4_kernel(const float* __restrict__
       float ssum = 0.f;
 #pragma unroll
       for (int c = 0; c < CM; ++c)
-        if (c < C) { x[c] = expf(x[c] - m); ssum += x[c]; }
+        if (c < C) { x[c] = __expf(x[c] - m); ssum += x[c]; }
+      const float rs = 1.f / ssum;
       int pred = 0;
       float pbest = -1.f;
 #pragma unroll
       for (int c = 0; c < CM; ++c)
         if (c < C) {
-          x[c] = x[c] / ssum;
+          x[c] = x[c] * rs;
           if (x[c] > pbest) { pbest = x[c]; pred = c; }
         }
       const float w = ok ? (weight ? weight[y] : 1.f) : 0.f;
@@ -313,15 +315,16 @@ __global__ __launch_bounds__(256) void ce_main_nhwc_kernel(const T* __restrict__
     for (int c = 0; c < LD; ++c)
       if (c < C) {
         if (c == y) xy = x[c];
-        x[c] = expf(x[c] - m);
+        x[c] = __expf(x[c] - m);
         ssum += x[c];
       }
+    const float rs = 1.f / ssum;
     int pred = 0;
     float pbest = -1.f;
 #pragma unroll
     for (int c = 0; c < LD; ++c)
       if (c < C) {
-        x[c] = x[c] / ssum;
+        x[c] = x[c] * rs;
         if (x[c] > pbest) { pbest = x[c]; pred = c; }
       }
     const float w = ok ? (weight ? weight[y] : 1.f) : 0.f;

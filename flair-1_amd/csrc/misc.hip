@@ -20,14 +20,14 @@ template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, unsigned char* __restrict__ idx,
                                    int N, int H, int W, int C) {
   constexpr int CH = Elem<T>::CH;
+  // one workgroup per output row (n, ho): 32-bit index arithmetic (the flat 64-bit div / mod chain of round 1 was a third of
+  // this kernel's ~750 vector instructions per item — it ran at 3.2 TB/s, issue-bound)
   const int Ho = H / 2, Wo = W / 2, cpr = C / CH;
-  const long total = (long)N * Ho * Wo * cpr;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int cx = (int)(i % cpr);
-    long p = i / cpr;
-    const int wo = (int)(p % Wo); p /= Wo;
-    const int ho = (int)(p % Ho);
-    const int n = (int)(p / Ho);
+  const int ho = blockIdx.x % Ho, n = blockIdx.x / Ho;
+  const unsigned row_items = (unsigned)Wo * cpr;
+  for (unsigned it = threadIdx.x; it < row_items; it += blockDim.x) {
+    const int cx = (int)(it % (unsigned)cpr), wo = (int)(it / (unsigned)cpr);
+    const long i = ((long)blockIdx.x * Wo + wo) * cpr + cx;
     float best[CH];
     unsigned char bi[CH];
 #pragma unroll
@@ -68,13 +68,11 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dout, const unsigned ch
                                    T* __restrict__ din, int accumulate, int N, int H, int W, int C) {
   constexpr int CH = Elem<T>::CH;
   const int Ho = H / 2, Wo = W / 2, cpr = C / CH;
-  const long total = (long)N * H * W * cpr;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int cx = (int)(i % cpr);
-    long p = i / cpr;
-    const int w = (int)(p % W); p /= W;
-    const int h = (int)(p % H);
-    const int n = (int)(p / H);
+  const int h = blockIdx.x % H, n = blockIdx.x / H;   // one workgroup per input row, 32-bit index arithmetic
+  const unsigned row_items = (unsigned)W * cpr;
+  for (unsigned it = threadIdx.x; it < row_items; it += blockDim.x) {
+    const int cx = (int)(it % (unsigned)cpr), w = (int)(it / (unsigned)cpr);
+    const long i = ((long)blockIdx.x * W + w) * cpr + cx;
     float g[CH];
     if (accumulate) chunk_to_f<T>(*reinterpret_cast<const uint4*>(din + i * CH), g);
     else {
@@ -353,12 +351,11 @@ __global__ void ew_add_kernel(T* __restrict__ dst, const T* __restrict__ src, lo
 int maxpool3x3s2_fwd(int dtype, const void* in, void* out, unsigned char* idx, int N, int H, int W, int C, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C % ch || (H & 1) || (W & 1)) return -2;
-  const long total = (long)N * (H / 2) * (W / 2) * (C / ch);
   ProfScope ps("maxpool_fwd", 0.0, (double)N * H * W * C * dtype_size(dtype) * 1.25 + (double)N * H * W * C / 4, s);
   if (dtype == DT_F32)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, (float*)out, idx, N, H, W, C);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(N * (H / 2)), dim3(256), 0, s, (const float*)in, (float*)out, idx, N, H, W, C);
   else
-    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, idx, N, H, W, C);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(N * (H / 2)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, idx, N, H, W, C);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }
@@ -367,12 +364,11 @@ int maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, void
                      int W, int C, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C % ch || (H & 1) || (W & 1)) return -2;
-  const long total = (long)N * H * W * (C / ch);
   ProfScope ps("maxpool_bwd", 0.0, (double)N * H * W * C * (dtype_size(dtype) * (1.25 + accumulate) + 0.25), s);
   if (dtype == DT_F32)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)dout, idx, (float*)din, accumulate, N, H, W, C);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(N * H), dim3(256), 0, s, (const float*)dout, idx, (float*)din, accumulate, N, H, W, C);
   else
-    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)dout, idx, (bf16_t*)din, accumulate, N, H, W, C);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(N * H), dim3(256), 0, s, (const bf16_t*)dout, idx, (bf16_t*)din, accumulate, N, H, W, C);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }
