@@ -161,7 +161,14 @@ struct WgradArgs {
   const float* in_shift;                             // small-channel halo kernel only
   int cus;                                           // persistent workgroups (= CUs) the register-resident kernel may occupy;
                                                      // 0 = the whole chip.  The executor gives its side stream half of it.
+  // optional bias gradient of the same layer, dbias[k] = sum_p dY[p][k], folded into the small-channel weight-gradient
+  // kernel (it stages every dY tile anyway; the head's separate column-sum pass read 268 MB for 13 numbers):
+  // dbias_partial = [dy_ld][WGRAD_DBIAS_ROWS] floats of scratch.  Ask wgrad_dbias_fusable() first.
+  float* dbias;
+  float* dbias_partial;
 };
+constexpr int WGRAD_DBIAS_ROWS = 1024;
+bool wgrad_dbias_fusable(int dtype, const WgradArgs& a);
 int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);
 size_t wgrad_workspace_bytes(int dtype, const WgradArgs& a);
 

@@ -682,14 +682,18 @@ void UNet::head_bwd_impl(const void* dl) {
   w.dy = dl; w.dy_ld = c.Cout_p; w.Cout = c.Cout; w.dw = grads_ + c.w_off; w.Cin_real = c.Cin;
   w.in_scale = dec_out_.lz_scale; w.in_shift = dec_out_.lz_shift;
   w.partial = (float*)alloc(wgrad_workspace_bytes(dtype, w));
+  // bias gradient = column sums of dl: inside the weight-gradient kernel where it stages dl anyway, else a pass of its own
+  const bool fuse_db = wgrad_dbias_fusable(dtype, w);
+  if (fuse_db) { w.dbias = grads_ + c.b_off; w.dbias_partial = alloc_f((long)WGRAD_DBIAS_ROWS * c.Cout_p); }
   {
     hipStream_t ws = wgrad_stream();
     RUN(launch_wgrad(dtype, w, ws));
   }
-  // bias gradient = column sums of dl
-  const long rows = dec_out_.rows();
-  float* partial = alloc_f((long)bn_bwd_blocks(rows) * c.Cout_p);
-  RUN(colsum(dtype, dl, rows, c.Cout_p, c.Cout, partial, grads_ + c.b_off, s_));
+  if (!fuse_db) {
+    const long rows = dec_out_.rows();
+    float* partial = alloc_f((long)bn_bwd_blocks(rows) * c.Cout_p);
+    RUN(colsum(dtype, dl, rows, c.Cout_p, c.Cout, partial, grads_ + c.b_off, s_));
+  }
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.src0 = dl; a.C0 = c.Cout_p; a.N = dec_out_.N; a.Hin = dec_out_.H; a.Win = dec_out_.W;

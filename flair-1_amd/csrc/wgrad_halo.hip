@@ -10,6 +10,7 @@
 #include "common.h"
 #include "prof.h"
 #include "tune.h"
+#include "ops.h"
 
 namespace flair {
 
@@ -70,6 +71,7 @@ struct WgHaloArgs {
   int Cout_pad, Kg;
   int ntiles;
   const float* in_scale; const float* in_shift;   // lazy BN + ReLU on x (WgradArgs::in_scale)
+  float* dbias_partial;   // [CO][gridDim.x] column sums of dY per workgroup (DB variants: one input- and one output-channel block)
 };
 
 template <typename T, int CK, int CO>
@@ -89,7 +91,8 @@ struct WgHaloCfg {
   static constexpr int DITEMS = (TH * TW * DPP + 255) / 256;
 };
 
-template <typename T, int CK, int CO, bool LZ>
+// DB: also the bias gradient (column sums of dY), summed from the staged dY chunks: a thread always stages the same chunk column
+template <typename T, int CK, int CO, bool LZ, bool DB = false>
 __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) {
   using Cfg = WgHaloCfg<T, CK, CO>;
   constexpr int CH = Cfg::CH, CPP = Cfg::CPP, DPP = Cfg::DPP, COT = Cfg::COT, CIT = Cfg::CIT;
@@ -169,6 +172,12 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
   };
   load_tile(blockIdx.x, xrA, drA, xbitsA, dbitsA);
   load_tile(blockIdx.x + gridDim.x, xrB, drB, xbitsB, dbitsB);
+  float bsum[CH];
+  if constexpr (DB) {
+    static_assert(256 % DPP == 0, "a thread keeps one dY chunk column");
+#pragma unroll
+    for (int e = 0; e < CH; ++e) bsum[e] = 0.f;
+  }
   auto do_tile = [&](int tile, u32x4 (&xr)[Cfg::XITEMS], u32x4 (&dr)[Cfg::DITEMS], unsigned& xbits, unsigned& dbits) {
     __syncthreads();  // the previous tile's fragment reads are done
 #pragma unroll
@@ -185,7 +194,14 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
       const int it = t + 256 * k;
       if (it < TH * TW * DPP) {
         const int px = it / DPP, ch = it - px * DPP;
-        *reinterpret_cast<u32x4*>(dyt + px * Cfg::DSTRIDE + ch * 16) = dr[k] & (0u - ((dbits >> k) & 1u));
+        const u32x4 dv = dr[k] & (0u - ((dbits >> k) & 1u));
+        *reinterpret_cast<u32x4*>(dyt + px * Cfg::DSTRIDE + ch * 16) = dv;
+        if constexpr (DB) {
+          float f[CH];
+          chunk_to_f<T>(__builtin_bit_cast(uint4, dv), f);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) bsum[e] += f[e];
+        }
       }
     }
     load_tile(tile + 2 * gridDim.x, xr, dr, xbits, dbits);   // the slot just staged is free
@@ -212,6 +228,19 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
     if (tile + gridDim.x < a.ntiles) do_tile(tile + gridDim.x, xrB, drB, xbitsB, dbitsB);
   }
 
+  if constexpr (DB) {   // workgroup sum of the staged dY columns, fixed order
+    __syncthreads();
+    float* bs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) bs[t * CH + e] = bsum[e];
+    __syncthreads();
+    if (t < CO) {
+      const int chunk = t / CH, e = t - chunk * CH;
+      float x = 0.f;
+      for (int th = chunk; th < 256; th += DPP) x += bs[th * CH + e];
+      a.dbias_partial[(long)(kbase + t) * gridDim.x + blockIdx.x] = x;
+    }
+  }
   // ---- merge the K parts (fixed order kp 0 <- 1, 2, 3), then one slab per workgroup
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);
@@ -246,10 +275,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const WgHaloArgs a) 
   }
 }
 
-template <typename T, int CK, int CO, bool LZ>
+template <typename T, int CK, int CO, bool LZ, bool DB = false>
 int launch_wg_halo_l(const WgHaloArgs& a, int nsplit, hipStream_t s) {
   using Cfg = WgHaloCfg<T, CK, CO>;
-  auto kern = wgrad3x3_halo_kernel<T, CK, CO, LZ>;
+  auto kern = wgrad3x3_halo_kernel<T, CK, CO, LZ, DB>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
@@ -294,6 +323,9 @@ int wg_halo_per_cu_t(int CK, int CO, bool lz) {
 
 template <typename T, int CK, int CO>
 int launch_wg_halo(const WgHaloArgs& a, int nsplit, hipStream_t s) {
+  if constexpr (CK == 16 && CO == 16) {
+    if (a.dbias_partial) return a.in_scale ? launch_wg_halo_l<T, CK, CO, true, true>(a, nsplit, s) : launch_wg_halo_l<T, CK, CO, false, true>(a, nsplit, s);
+  }
   return a.in_scale ? launch_wg_halo_l<T, CK, CO, true>(a, nsplit, s) : launch_wg_halo_l<T, CK, CO, false>(a, nsplit, s);
 }
 
@@ -344,6 +376,11 @@ int launch_wgrad_halo(int dtype, const WgradArgs& a, hipStream_t s) {
   h.dy = a.dy; h.dy_ld = a.dy_ld; h.Cout = a.Cout; h.partial = a.partial; h.Cout_pad = Cout_pad; h.Kg = 9 * Cin;
   h.ntiles = (int)((long)a.N * a.Hin * a.Win / (TH * TW));
   h.in_scale = a.in_scale; h.in_shift = a.in_shift;
+  h.dbias_partial = nullptr;
+  if (a.dbias) {
+    if (!wgrad_dbias_fusable(dtype, a) || !a.dbias_partial || nsplit > WGRAD_DBIAS_ROWS) return -6;
+    h.dbias_partial = a.dbias_partial;
+  }
   int rc;
   if (dtype == DT_F32) {
     if (CK == 16) rc = CO == 16 ? launch_wg_halo<float, 16, 16>(h, nsplit, s) : launch_wg_halo<float, 16, 32>(h, nsplit, s);
@@ -354,8 +391,20 @@ int launch_wgrad_halo(int dtype, const WgradArgs& a, hipStream_t s) {
   }
   if (rc) return rc;
   launch_wgrad_reduce(a.partial, a.dw, nsplit, a.Cout, Cout_pad, 9 * Cin, Cin, a.Cin_real, 3, 3, a.accumulate, s);
+  if (h.dbias_partial) {
+    rc = partial_rows_sum(h.dbias_partial, nsplit, a.Cout, a.dbias, s);
+    if (rc) return rc;
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+// the 16 -> <= 16 channel layers (one input- and one output-channel block per workgroup: every dY tile is staged exactly once)
+bool wgrad_dbias_fusable(int dtype, const WgradArgs& a) {
+  int CK, CO, ns, cp;
+  if (!tune("FLAIR_DBIAS_FUSE", 1) || !wg_halo_geom(-1, a, CK, CO, ns, cp)) return false;
+  (void)dtype;
+  return CK == 16 && CO == 16 && cp == 16 && a.C0 + a.C1 == 16 && a.dy_ld == 16;
 }
 
 }  // namespace flair
