@@ -278,7 +278,7 @@ struct HaloPCfg {
   static constexpr int SMEM = SOFF + B::STATS;   // no C tile: the epilogue goes from registers to HBM (tile_direct.h)
 };
 
-template <typename T, int CK, int BN, bool LZ>
+template <typename T, int CK, int BN, bool LZ, bool BNR = false>
 __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, int ntiles) {
   using Cfg = HaloCfg<T, CK, BN>;
   using PC = HaloPCfg<T, CK, BN>;
@@ -323,6 +323,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
   float s1[4 * TN], s2[4 * TN];
 #pragma unroll
   for (int e = 0; e < 4 * TN; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  DirectBnr<TN> bn;
+  if constexpr (BNR) bn.init(a, 0, lq);
 
   // Two register slots: the halo of tile i + 2 is requested while tile i is multiplied (the MFMA phase of a 16-32-channel tile
   // is ~0.3 us, an HBM round trip under load ~2 us: with one slot every iteration waited for its loads)
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
       const int n = tile / (tiles_x * tiles_y);
       const int trem = tile - n * tiles_x * tiles_y;
       const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
-      direct_store<T, TW, TN>(a, acc, n, y0, x0, 0, wave, lane, cf, s1, s2);
+      direct_store<T, TW, TN, !BNR, BNR>(a, acc, n, y0, x0, 0, wave, lane, cf, s1, s2, &bn);   // (a data gradient has no affine / statistics)
     }
     __syncthreads();   // every wave is done with the halo
     halo_store(stg, stbits);
@@ -408,6 +410,18 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
   for (int tile = blockIdx.x; tile < ntiles; tile += 2 * gridDim.x) {
     do_tile(tile, hregA, hbitsA, hregB, hbitsB);   // slot A went to LDS before this tile; B holds the next one
     if (tile + gridDim.x < ntiles) do_tile(tile + gridDim.x, hregB, hbitsB, hregA, hbitsA);
+  }
+  if constexpr (BNR) {   // one partial per workgroup and channel, like the statistics: [2][bnr_C][gridDim.x]
+    direct_stats_wave<TN>(bn.r1, bn.r2, st, BN, 0, wave, lane);
+    __syncthreads();
+    if (t < BN && t < a.bnr_C) {
+      float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { x1 += st[(w * BN + t) * 2]; x2 += st[(w * BN + t) * 2 + 1]; }
+      a.bnr_partial[(long)t * gridDim.x + blockIdx.x] = x1;
+      a.bnr_partial[((long)a.bnr_C + t) * gridDim.x + blockIdx.x] = x2;
+    }
+    return;
   }
   if (a.stats) {
     direct_stats_wave<TN>(s1, s2, st, BN, 0, wave, lane);
@@ -422,16 +436,25 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
   }
 }
 
+bool halo_persistent(const ConvArgs& a);
+// the fused BatchNorm-backward reduction of the persistent single-block kernel: a plain data gradient (no affine, statistics,
+// residual, NCHW copy), mask from y, and an output row that IS the unit's channel row
+static bool conv_halo_bnr_ok(const ConvArgs& a) {
+  return tune("FLAIR_BNR_HALO", 1) && halo_persistent(a) && !a.in_scale && !a.stats && !a.oscale && !a.oshift && !a.bias && !a.ores && !a.orelu &&
+         !a.out_nchw && !a.bnr_out && a.bnr_y && a.bnr_C == a.out_ld && a.bnr_C <= 32 && a.bnr_C <= (a.Cout <= 16 ? 16 : 32) &&
+         (a.pool_c0 == 0 || a.pool_c0 == a.Cout);
+}
+
 // persistent grid = the workgroups that are resident at once (registers and LDS: asked from the runtime once per variant; a
 // grid above that runs its surplus as a second, unbalanced round — 16 -> 16 at 512^2: 141 us with 4 per CU against 125 with the
 // 3 that fit).  Without a device (planning on a CPU-only host) the LDS bound stands in.
-template <typename T, int CK, int BN, bool LZ>
+template <typename T, int CK, int BN, bool LZ, bool BNR = false>
 int halo_p_per_cu() {
   static const int per_cu = [] {
     int lds = (160 * 1024) / HaloPCfg<T, CK, BN>::SMEM;
     lds = lds > 4 ? 4 : (lds < 1 ? 1 : lds);
     int nb = 0;
-    auto kern = conv3x3_halo_p_kernel<T, CK, BN, LZ>;
+    auto kern = conv3x3_halo_p_kernel<T, CK, BN, LZ, BNR>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HaloPCfg<T, CK, BN>::SMEM) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, HaloPCfg<T, CK, BN>::SMEM) != hipSuccess || nb < 1) {
       (void)hipGetLastError();
@@ -446,14 +469,15 @@ int halo_p_per_cu() {
 template <typename T, int CK, int BN>
 int halo_p_blocks(const ConvArgs& a) {
   const long ntiles = (long)a.N * a.Hout * a.Wout / (TH * TW);
-  const long cap = 256L * (a.in_scale ? halo_p_per_cu<T, CK, BN, true>() : halo_p_per_cu<T, CK, BN, false>());
+  const long cap = 256L * (a.bnr_partial ? halo_p_per_cu<T, CK, BN, false, true>()
+                                         : a.in_scale ? halo_p_per_cu<T, CK, BN, true>() : halo_p_per_cu<T, CK, BN, false>());
   return (int)(ntiles < cap ? ntiles : cap);
 }
 
-template <typename T, int CK, int BN, bool LZ>
+template <typename T, int CK, int BN, bool LZ, bool BNR = false>
 int launch_halo_p_l(const ConvArgs& a, hipStream_t s) {
   using PC = HaloPCfg<T, CK, BN>;
-  auto kern = conv3x3_halo_p_kernel<T, CK, BN, LZ>;
+  auto kern = conv3x3_halo_p_kernel<T, CK, BN, LZ, BNR>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM);
@@ -475,6 +499,7 @@ int launch_halo_p_l(const ConvArgs& a, hipStream_t s) {
 
 template <typename T, int CK, int BN>
 int launch_halo_p(const ConvArgs& a, hipStream_t s) {
+  if (a.bnr_partial) return conv_halo_bnr_ok(a) ? launch_halo_p_l<T, CK, BN, false, true>(a, s) : -6;
   return a.in_scale ? launch_halo_p_l<T, CK, BN, true>(a, s) : launch_halo_p_l<T, CK, BN, false>(a, s);
 }
 
@@ -705,6 +730,8 @@ static int halo_rows_t(const ConvArgs& a) {
   if (Cin == 16) return n16 ? halo_p_blocks<T, 16, 16>(a) : halo_p_blocks<T, 16, 32>(a);
   return n16 ? halo_p_blocks<T, 32, 16>(a) : halo_p_blocks<T, 32, 32>(a);
 }
+
+bool conv_halo_bnr_applicable(const ConvArgs& a) { return conv_halo_applicable(a) && conv_halo_bnr_ok(a); }
 
 int conv_halo_grid_rows(int dtype, const ConvArgs& a) {
   if (halo_persistent_multi(dtype, a)) return halo_pm_blocks<bf16_t, 32, 32, 4>(a);

@@ -340,6 +340,7 @@ static inline int pick_bm(int cout) { return cout >= 64 ? 128 : 256; }
 bool conv_halo_applicable(const ConvArgs& a);           // conv_halo.hip
 int conv_halo_grid_rows(int dtype, const ConvArgs& a);
 int launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s);
+bool conv_halo_bnr_applicable(const ConvArgs& a);
 bool conv_stem_applicable(int dtype, const ConvArgs& a);  // stem.hip
 int conv_stem_grid_rows(const ConvArgs& a);
 int launch_conv_stem(const ConvArgs& a, hipStream_t s);
@@ -361,7 +362,9 @@ bool conv_mfma_bound(int dtype, const ConvArgs& a) {
     const char* e = getenv("FLAIR_BNR");
     mode = e ? atoi(e) : 2;
   }
-  if (mode == 0 || !conv_hg_applicable(dtype, a)) return false;
+  if (mode == 0) return false;
+  if (!conv_hg_applicable(dtype, a)) return conv_halo_bnr_applicable(a);   // (not MFMA-bound: the persistent small-channel kernel
+                                                                           // saves the reduce pass's read of the gradient)
   return mode == 2 || (a.Cout % 128) == 0;
 }
 
@@ -407,7 +410,7 @@ int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
     return launch_conv_halo(dtype, a, s);
   }
   if (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a)) return -6;
-  if (a.bnr_partial && !(conv_tile_epilogue_ok(dtype, a) && conv_hg_applicable(dtype, a))) return -6;  // halo-GEMM epilogue only
+  if (a.bnr_partial && !(conv_tile_epilogue_ok(dtype, a) && (conv_hg_applicable(dtype, a) || conv_halo_bnr_applicable(a)))) return -6;
   if (conv_stem_applicable(dtype, a)) return launch_conv_stem(a, s);     // 7x7 stride-2 stem
   if (conv_hg_applicable(dtype, a)) return launch_conv_hg(dtype, a, s);  // MFMA-bound 3x3 s1 layers: halo GEMM
   if (conv_halo_applicable(a)) {  // HBM-bound small-channel 3x3 layers: halo-tile direct kernel

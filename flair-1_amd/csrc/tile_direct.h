@@ -80,10 +80,38 @@ struct DirectCoef {
 // One 8x32 tile of one column block (16*TN channels from n0): acc[i][q] = block (tile row 2*wave + (i >> 1), pixels
 // (i & 1)*16 .. +15) x (weight rows q*16 .. +15), element [rr] = row 4*lq + rr of pixel lr = channel n0 + 4*TN*lq + q*4 + rr.
 // s1 / s2: running per-lane BatchNorm sums of the ROUNDED outputs (statistics of what the next layer reads).
+// Fused first pass of the upstream unit's BatchNorm backward (ConvArgs::bnr_*, mask from y): per-lane state of one column block
+template <int TN>
+struct DirectBnr {
+  float msc[4 * TN], msh[4 * TN], r1[4 * TN], r2[4 * TN];
+  __device__ __forceinline__ void init(const ConvArgs& a, int n0, int lq) {
+#pragma unroll
+    for (int e = 0; e < 4 * TN; ++e) {
+      const int col = n0 + 4 * TN * lq + e;
+      r1[e] = 0.f; r2[e] = 0.f;
+      msc[e] = col < a.bnr_C ? a.bnr_scale[col] : 0.f;
+      msh[e] = col < a.bnr_C ? a.bnr_shift[col] : 0.f;
+    }
+  }
+  // f: the values just stored (rounded here as store_tile's bnr_item sees them), y: the unit's pre-BN tensor at the same place
+  template <typename T>
+  __device__ __forceinline__ void item(const float* f, const float* y) {
+#pragma unroll
+    for (int e = 0; e < 4 * TN; ++e) {
+      const float d = Elem<T>::to_f(Elem<T>::from_f(f[e]));
+      const float dm = fmaf(y[e], msc[e], msh[e]) > 0.f ? d : 0.f;
+      r1[e] += dm;
+      r2[e] = fmaf(dm, y[e], r2[e]);
+    }
+  }
+};
+
 // AFF = false: no per-channel affine and no statistics (plain data gradients): cf / s1 / s2 are not touched
-template <typename T, int TW_, int TN, bool AFF = true>
+// BNR: `bn` accumulates sum(dz*m), sum(dz*m*y) of the stored gradient (the pooled half when pool_c0 > 0)
+template <typename T, int TW_, int TN, bool AFF = true, bool BNR = false>
 __device__ __forceinline__ void direct_store(const ConvArgs& a, const f32x4_t (&acc)[4][TN], int n, int y0, int x0, int n0, int wave,
-                                             int lane, const DirectCoef<TN>& cf, float (&s1)[4 * TN], float (&s2)[4 * TN]) {
+                                             int lane, const DirectCoef<TN>& cf, float (&s1)[4 * TN], float (&s2)[4 * TN],
+                                             DirectBnr<TN>* bn = nullptr) {
   constexpr int CH = Elem<T>::CH, NCH = 4 * TN;
   typedef LaneVec<T, NCH> LV;
   const int lr = lane & 15, lq = lane >> 4;
@@ -138,6 +166,11 @@ __device__ __forceinline__ void direct_store(const ConvArgs& a, const f32x4_t (&
           for (int e = 0; e < NCH; ++e) f[e] += g[e];
         }
         LV::store(dst, f);
+        if constexpr (BNR) {
+          float yv[NCH];
+          LV::load((const T*)a.bnr_y + (dst - out), yv);
+          bn->template item<T>(f, yv);
+        }
       }
     }
     return;
@@ -177,6 +210,13 @@ __device__ __forceinline__ void direct_store(const ConvArgs& a, const f32x4_t (&
       for (int e = 0; e < NCH; ++e) f[e] += g[e];
     }
     LV::store(dst, f);
+    if constexpr (BNR) {
+      if (a.pool_c0 == 0) {   // (with pool_c0 > 0 only the pooled half is the upstream unit's gradient)
+        float yv[NCH];
+        LV::load((const T*)a.bnr_y + goff, yv);
+        bn->template item<T>(f, yv);
+      }
+    }
   }
 }
 
