@@ -157,7 +157,9 @@ bool UNet::side_init() {
 // caller's stream runs dry, the whole chip again: +0.05 ... +0.3 ms).
 int UNet::side_cus(int) const {
   if (!tune("FLAIR_WGRAD_STREAM", 1)) return 0;
-  return tune("FLAIR_WG_CUS", 128);
+  // fp32 mode: everything is matrix-pipe-bound there (fp32 MFMA is 16x slower), the BatchNorm kernels are a small share and
+  // halving the weight-gradient kernels' CUs costs more than it frees: 57.4 ms with the whole chip, 58.4 with 192, 62.2 with 128
+  return tune("FLAIR_WG_CUS", dtype == DT_F32 ? 256 : 128);
 }
 
 hipStream_t UNet::wgrad_stream() {
