@@ -216,15 +216,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs ka) {
 }
 
 // dw[k][c][r][s] (+)= sum_z partial[z][k][(r*S+s)*Cin + c]
-// 64 consecutive elements x 4 slab groups per workgroup: coalesced 256-byte slab reads, four independent
-// partial sums per thread in flight, fixed summation order (group-major) -> bit-reproducible.
+// EL consecutive elements x G = 256 / EL slab groups per workgroup, four independent partial sums per thread in flight, fixed
+// summation order (group-major) -> bit-reproducible.  EL = 64 / G = 4: coalesced 256-byte slab reads for the large gradients;
+// EL = 16 / G = 16 for the small-channel layers' many slabs of a tiny gradient (the head: 1024 slabs of 13 x 144 — with G = 4 that
+// was 30 workgroups and 64 dependent round trips per thread, 43 us for 9 MB).
+template <int EL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits,
                                                            int Cout, int Cout_pad, int Kpad, int Cin, int Cin_real, int R,
                                                            int S, int accumulate) {
-  __shared__ float sh[4][64];
+  constexpr int G = 256 / EL;
+  __shared__ float sh[G][EL];
   const long total = (long)Cout * R * S * Cin;
-  const int e = threadIdx.x & 63, zg = threadIdx.x >> 6;
-  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+  const int e = threadIdx.x % EL, zg = threadIdx.x / EL;
+  for (long base = (long)blockIdx.x * EL; base < total; base += (long)gridDim.x * EL) {
     const long idx = base + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0, kk = 0;
@@ -234,15 +238,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       const float* p = part + (long)k * Kpad + kk;
       const long zs = (long)Cout_pad * Kpad;
       int z = zg;
-      for (; z + 12 < splits; z += 16) {
-        s0 += p[(long)z * zs]; s1 += p[(long)(z + 4) * zs]; s2 += p[(long)(z + 8) * zs]; s3 += p[(long)(z + 12) * zs];
+      for (; z + 3 * G < splits; z += 4 * G) {
+        s0 += p[(long)z * zs]; s1 += p[(long)(z + G) * zs]; s2 += p[(long)(z + 2 * G) * zs]; s3 += p[(long)(z + 3 * G) * zs];
       }
-      for (; z < splits; z += 4) s0 += p[(long)z * zs];
+      for (; z < splits; z += G) s0 += p[(long)z * zs];
     }
     sh[zg][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (zg == 0 && idx < total) {
-      const float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; g += 4) s += (sh[g][e] + sh[g + 1][e]) + (sh[g + 2][e] + sh[g + 3][e]);
       const int tap = kk / Cin, c = kk - tap * Cin;
       if (c < Cin_real) {
         const int r = tap / S, q = tap - r * S;
@@ -289,10 +295,16 @@ int launch_wgrad_big(int dtype, const WgradArgs& a, hipStream_t s);
 void launch_wgrad_reduce(const float* partial, float* dw, int splits, int Cout, int Cout_pad, int Kpad, int Cin,
                          int Cin_real, int R, int S, int accumulate, hipStream_t s) {
   const long total = (long)Cout * R * S * Cin;
+  ProfScope ps("wgrad_reduce", 0.0, ((double)splits + 1.0) * total * 4.0, s);
+  if (splits >= 64 && total <= 65536) {   // many slabs of a small gradient
+    int blocks = cdiv(total, 16);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, s, partial, dw, splits, Cout, Cout_pad, Kpad, Cin,
+                       Cin_real, R, S, accumulate);
+    return;
+  }
   int blocks = cdiv(total, 64);
   if (blocks > 8192) blocks = 8192;
-  ProfScope ps("wgrad_reduce", 0.0, ((double)splits + 1.0) * total * 4.0, s);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, splits, Cout, Cout_pad, Kpad, Cin,
+  hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(blocks), dim3(256), 0, s, partial, dw, splits, Cout, Cout_pad, Kpad, Cin,
                      Cin_real, R, S, accumulate);
 }
 
