@@ -346,6 +346,9 @@ def main():
         if prof:
             tot = sum(r["ms"] for r in prof)
             res["roofline"] = roofline_obj(prof, args, full_workload)
+            res["roofline"]["note"] = ("timed region as it runs: in backward this kernel shares the chip with the persistent weight-gradient "
+                                       "kernel of the side stream (space sharing, 128 of 256 CUs in bf16 mode); `roofline_alone` is the "
+                                       "same kernel with every CU")
             # sum over BOTH streams (weight gradients run beside the BN / data-gradient chain): exceeds ms_per_step
             res["kernel_time_ms_per_step"] = round(tot, 3)
             res["kernel_time_note"] = "sum of per-kernel HIP-event times over two overlapping streams"
