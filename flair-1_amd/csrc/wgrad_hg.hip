@@ -11,6 +11,7 @@
 // summed in a fixed order by wgrad_reduce_kernel.
 #include "common.h"
 #include "prof.h"
+#include "tune.h"
 
 namespace flair {
 
@@ -125,15 +126,12 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
 
   u32x4 xr[Cfg::XITEMS], dr[Cfg::DITEMS];
   unsigned xm[Cfg::XITEMS];
-  float lsc[CH], lsh[CH];
+  unsigned dmask = 0u;
   const bool lz = LZ && use0 && a.in_scale != nullptr;
-  if constexpr (LZ) {
-#pragma unroll
-    for (int e = 0; e < CH; ++e) {
-      lsc[e] = lz ? a.in_scale[coff + (t & 7) * CH + e] : 1.f;
-      lsh[e] = lz ? a.in_shift[coff + (t & 7) * CH + e] : 0.f;
-    }
-  }
+  // (the lazy transform's coefficients are re-read from L1 when a halo is staged: held in registers for the whole kernel they
+  // were the 16 registers the pipelined multiply phase then spilled)
+  const float* __restrict__ lzs = lz ? a.in_scale + coff + (t & 7) * CH : nullptr;
+  const float* __restrict__ lzh = lz ? a.in_shift + coff + (t & 7) * CH : nullptr;
   auto load_tile = [&](int tile) {
     const bool tok = tile < a.ntiles;
     const int tl = tok ? tile : 0;
@@ -158,12 +156,18 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
       const int py = px / TW, pxx = px - py * TW;
       const unsigned off = (unsigned)(((n * H + y0 + py) * W + x0p + pxx) * a.dy_ld + kbase + ch * CH);
       dr[k] = *reinterpret_cast<const u32x4*>(dy + (tok ? off : 0u));
-      if (!tok) dr[k] = u32x4{0u, 0u, 0u, 0u};
     }
+    dmask = tok ? 0xffffffffu : 0u;   // applied when the registers go to LDS: a select HERE would wait for the loads it masks
   };
-  auto store_tile = [&](int buf) {
+  auto store_x = [&](int buf) {
     unsigned char* xh = smem + buf * Cfg::STAGE;
-    unsigned char* dyt = xh + Cfg::XBYTES;
+    float lsc[CH], lsh[CH];
+    if constexpr (LZ) {
+      if (lz) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { lsc[e] = lzs[e]; lsh[e] = lzh[e]; }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < Cfg::XITEMS; ++k) {
       const int it = t + NT * k;
@@ -175,20 +179,29 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
         *reinterpret_cast<u32x4*>(xh + (it >> 3) * Cfg::XSTRIDE + (it & 7) * 16) = xv & xm[k];
       }
     }
+  };
+  auto store_d = [&](int buf) {
+    unsigned char* dyt = smem + buf * Cfg::STAGE + Cfg::XBYTES;
 #pragma unroll
     for (int k = 0; k < Cfg::DITEMS; ++k) {
       const int it = t + NT * k;
-      *reinterpret_cast<u32x4*>(dyt + (it / DCH) * Cfg::DSTRIDE + (it % DCH) * 16) = dr[k];
+      *reinterpret_cast<u32x4*>(dyt + (it / DCH) * Cfg::DSTRIDE + (it % DCH) * 16) = dr[k] & dmask;
     }
   };
 
+  // Staging is folded INTO the multiply phase (round 2b): while tile i is multiplied from LDS buffer i & 1, the registers hold
+  // tile i + 1; its halo goes to the other buffer after the first K step, its dY tile after the second, and the loads of tile
+  // i + 2 are issued right behind — they have the rest of this tile and the first K step of the next to land.  Before, the
+  // ds_writes, the lazy transform and the address arithmetic of the next loads sat between the last MFMA and the barrier:
+  // 3.9 us per tile against 2.4 us of MFMA issue (`FLAIR_WG_DBG`-style timing).
   load_tile(blockIdx.x);
-  store_tile(0);
+  store_x(0); store_d(0);
+  load_tile(blockIdx.x + gridDim.x);
   __syncthreads();
   int it = 0;
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, ++it) {
-    load_tile(tile + gridDim.x);   // next tile rides in registers while this one is multiplied
-    __builtin_amdgcn_sched_barrier(0);  // pin the prefetch ahead of the MFMA phase (hipcc would sink it)
+    const int nbuf = (it + 1) & 1;
+    const int tile2 = tile + 2 * gridDim.x;
     const unsigned char* xh = smem + (it & 1) * Cfg::STAGE;
     const unsigned char* dyt = xh + Cfg::XBYTES;
     if constexpr (sizeof(T) == 2) {
@@ -196,8 +209,12 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
       // transposed-read addresses of pixels 8g+q and 8g+4+q of the step; in the halo image the second row
       // starts HW_ pixels later, in the dense dY image 16 pixels later.
       const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-      const int dpix = 8 * g + q;
-      const int xpix = (g >> 1) * HW_ + 8 * (g & 1) + q;
+#ifndef FLAIR_WG_KMAP
+#define FLAIR_WG_KMAP 1
+#endif
+      constexpr int pstep = FLAIR_WG_KMAP ? 2 : 1, hi_px = FLAIR_WG_KMAP ? 1 : 4;
+      const int dpix = 8 * g + pstep * q;
+      const int xpix = (g >> 1) * HW_ + 8 * (g & 1) + pstep * q;
       typedef __attribute__((address_space(3))) s16x4_t* lds_p;
       auto tr2 = [&](const unsigned char* lo_addr, int hi_delta) {
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo_addr));
@@ -209,22 +226,55 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
         r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
         return r;
       };
-#pragma unroll 1
-      for (int y = kg * YROWS; y < (kg + 1) * YROWS; y += 2) {
-        u32x4 af[COT];
+      // Fragment reads one tap ahead of the MFMAs, in two register sets pinned by scheduling fences (hipcc's own order read a
+      // tap's fragments and drained lgkmcnt right in front of its four MFMAs: the LDS latency of every tap was exposed, 3.9 us
+      // per tile against 2.4 us of MFMA issue)
+      auto rdb = [&](u32x4 (&bf)[CIT], int y, int tp) {
+        const int r = tp / 3, s = tp - 3 * r;
+#pragma unroll
+        for (int ci = 0; ci < CIT; ++ci)
+          bf[ci] = tr2(xh + (xpix + (y + r) * HW_ + s) * Cfg::XSTRIDE + (wc * CIT + ci) * 32 + 8 * p, hi_px * Cfg::XSTRIDE);
+      };
+      auto kstep = [&](int y) {
+        u32x4 af[COT], bfA[CIT], bfB[CIT];
 #pragma unroll
         for (int co = 0; co < COT; ++co)
-          af[co] = tr2(dyt + (y * TW + dpix) * Cfg::DSTRIDE + (wk * COT + co) * 32 + 8 * p, 4 * Cfg::DSTRIDE);
+          af[co] = tr2(dyt + (y * TW + dpix) * Cfg::DSTRIDE + (wk * COT + co) * 32 + 8 * p, hi_px * Cfg::DSTRIDE);
+        rdb(bfA, y, 0);
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-          const int r = tp / 3, s = tp - 3 * r;
+        for (int tp = 0; tp < 9; tp += 2) {
+          if (tp + 1 < 9) rdb(bfB, y, tp + 1);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int ci = 0; ci < CIT; ++ci) {
-            const u32x4 bf = tr2(xh + (xpix + (y + r) * HW_ + s) * Cfg::XSTRIDE + (wc * CIT + ci) * 32 + 8 * p, 4 * Cfg::XSTRIDE);
+          for (int ci = 0; ci < CIT; ++ci)
 #pragma unroll
-            for (int co = 0; co < COT; ++co) BFrag<T>::mma(af[co], bf, acc[co][ci][tp]);
+            for (int co = 0; co < COT; ++co) BFrag<T>::mma(af[co], bfA[ci], acc[co][ci][tp]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (tp + 1 < 9) {
+            if (tp + 2 < 9) rdb(bfA, y, tp + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ci = 0; ci < CIT; ++ci)
+#pragma unroll
+              for (int co = 0; co < COT; ++co) BFrag<T>::mma(af[co], bfB[ci], acc[co][ci][tp + 1]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
+      };
+      const int yb = kg * YROWS;
+      kstep(yb);
+      __builtin_amdgcn_sched_barrier(0);
+      store_x(nbuf);
+      if constexpr (KG == 2) { store_d(nbuf); load_tile(tile2); }
+      __builtin_amdgcn_sched_barrier(0);
+      kstep(yb + 2);
+      if constexpr (KG == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        store_d(nbuf);
+        load_tile(tile2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int y = yb + 4; y < yb + YROWS; y += 2) kstep(y);
       }
     } else {
 #pragma unroll 1
@@ -244,8 +294,9 @@ __global__ __launch_bounds__(512) void wgrad3x3_big_kernel(const WgBigArgs a) {
           }
         }
       }
+      store_x(nbuf); store_d(nbuf);
+      load_tile(tile2);
     }
-    store_tile((it + 1) & 1);
     __syncthreads();
   }
 
@@ -388,7 +439,7 @@ static bool wg_big_geom(int dtype, const WgradArgs& a, int& nsplit, int& kg) {
   if ((Cin % ck) || (a.C0 % ck) || (a.Cout % co) || a.dy_ld != a.Cout) return false;
   const long ntiles = (long)a.N * a.Hin * a.Win / TPIX;
   const int per = (Cin / ck) * (a.Cout / co);
-  long ns = (a.cus > 0 ? a.cus : 256) / per;   // one 8-wave workgroup per CU
+  long ns = (a.cus > 0 ? a.cus : tune("FLAIR_WG_CUS_OP", 256)) / per;   // one 8-wave workgroup per CU (the standalone operator: all of them)
   if (ns < 1) ns = 1;
   if (ns > ntiles) ns = ntiles;
   nsplit = (int)ns;
