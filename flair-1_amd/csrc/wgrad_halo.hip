@@ -30,8 +30,12 @@ template <> struct HFrag<bf16_t> {
   __device__ static __forceinline__ u32x4 load(const unsigned char* img, int row0, int cb, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     typedef __attribute__((address_space(3))) s16x4_t* lds_p;
-    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + (row0 + 8 * g + q) * STRIDE + cb + 8 * p));
-    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + (row0 + 8 * g + 4 + q) * STRIDE + cb + 8 * p));
+    // pixel -> K-slot map: the `lo` read takes the even pixels of the lane group's eight, the `hi` read the odd ones.  A
+    // 32-lane half then reads eight rows 2 * STRIDE apart: with STRIDE = 48 or 80 bytes they fall on disjoint bank octets
+    // (rows q, q + 4 put two rows on half of the banks: SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE, and the LDS was
+    // active 45-62 % of these kernels' time).  Both operands use the same map, the products are unchanged.
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + (row0 + 8 * g + 2 * q) * STRIDE + cb + 8 * p));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + (row0 + 8 * g + 2 * q + 1) * STRIDE + cb + 8 * p));
     u32x4 r;
     r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
     r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
