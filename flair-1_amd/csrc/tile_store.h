@@ -141,8 +141,22 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
   const int cbase = a.pool_c0 > 0 ? a.pool_c0 : 0;
   const int acc = a.pool_c0 > 0 ? a.skip_accumulate : a.accumulate;
   constexpr int ITEMS = TileItems<T, TPIX, BN, NT>::ITEMS;
-  uint4 yv[ITEMS], ov[ITEMS];
+  uint4 yv[ITEMS], ov[ITEMS], av[ITEMS];
   if (bnr) tile_bnr_prefetch<T, TW, TPIX, BN, NT>(a, n, y0, x0, n0, t, yv, ov);
+  if (acc) {
+    // all read-modify-write operands in flight together (inside the store loop the compiler cannot move a load above the
+    // previous item's store: eight dependent HBM round trips per thread in the epilogue of every accumulating data gradient)
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int idx = t + k * NT;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int py = row / TW, px = row - py * TW;
+      const int nn = n0 + ch * CH;
+      const bool ok = idx < TPIX * CPR && nn < a.Cout;
+      const long goff = ok ? ((long)(n * H + y0 + py) * W + x0 + px) * ld + (nn - cbase) : 0;
+      av[k] = *reinterpret_cast<const uint4*>(out + goff);
+    }
+  }
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const int idx = t + k * NT;
@@ -172,7 +186,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
       if (acc) {
         float fa[CH], fb[CH];
         chunk_to_f<T>(v, fa);
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(dst), fb);
+        chunk_to_f<T>(av[k], fb);
 #pragma unroll
         for (int e = 0; e < CH; ++e) fa[e] += fb[e];
         v = f_to_chunk<T>(fa);
