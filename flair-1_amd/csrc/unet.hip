@@ -159,7 +159,8 @@ int UNet::side_cus(int) const {
   if (!tune("FLAIR_WGRAD_STREAM", 1)) return 0;
   // fp32 mode: everything is matrix-pipe-bound there (fp32 MFMA is 16x slower), the BatchNorm kernels are a small share and
   // halving the weight-gradient kernels' CUs costs more than it frees: 57.4 ms with the whole chip, 58.4 with 192, 62.2 with 128
-  return tune("FLAIR_WG_CUS", dtype == DT_F32 ? 256 : 128);
+  const int v = tune("FLAIR_WG_CUS", 0);   // (tune() caches its default per key: the dtype-dependent default lives here)
+  return v > 0 ? v : (dtype == DT_F32 ? 256 : 128);
 }
 
 hipStream_t UNet::wgrad_stream() {
