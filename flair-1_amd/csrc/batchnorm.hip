@@ -448,6 +448,7 @@ int bn_backward(int dtype, const void* dout, const void* out, const void* y, con
                        mean, dgamma, dbeta, accumulate_param, k1, k2, k3);
   }
   FLAIR_CHECK_LAUNCH();
+  if (!dy && !dres) return 0;   // the consumer applies dy = k1*dz + k2*y + k3 itself (stem: inside its weight-gradient kernel)
   const long total = rows * (C / ch);
   ProfScope ps2("bn_bwd_apply", 0.0, (double)rows * C * dtype_size(dtype) * ((out ? 3 : 2) + 1 + (dres ? 1 : 0)), s);
   if (dtype == DT_F32)

@@ -166,7 +166,15 @@ struct WgradArgs {
   // dbias_partial = [dy_ld][WGRAD_DBIAS_ROWS] floats of scratch.  Ask wgrad_dbias_fusable() first.
   float* dbias;
   float* dbias_partial;
+  // optional fused BatchNorm-backward apply on dy (the stem's weight-gradient kernel only; ask wgrad_bnapply_fusable()): `dy` is
+  // then the gradient w.r.t. the unit's ReLU output, and the kernel stages  k1*dz + k2*y + k3,  dz = dy * [y*msc + msh > 0],
+  // with the rounding of bn_bwd_apply_kernel — the tensor bn_bwd_apply would have written is never materialised
+  const void* fuse_y;
+  const float* fuse_coef;   // k1 | k2 | k3, each Cout floats (bn_bwd_finalize_kernel)
+  const float* fuse_msc;
+  const float* fuse_msh;
 };
+bool wgrad_bnapply_fusable(int dtype, const WgradArgs& a);
 constexpr int WGRAD_DBIAS_ROWS = 1024;
 bool wgrad_dbias_fusable(int dtype, const WgradArgs& a);
 int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);

@@ -10,6 +10,7 @@
 // bf16 only; fp32 (the parity mode) stays on the generic kernel.
 #include "common.h"
 #include "prof.h"
+#include "tune.h"
 
 namespace flair {
 
@@ -34,8 +35,11 @@ struct StemWgArgs {
   const bf16_t* dy;   // [N][H][W][64]
   float* partial;     // [gridDim.x][64][392]
   int N, H, W, ntiles;
+  const bf16_t* y; const float* coef; const float* msc; const float* msh;   // FUSE: WgradArgs::fuse_*
 };
 
+// FUSE: dy holds the gradient w.r.t. the stem's ReLU output; the BatchNorm-backward apply runs on the dY chunks as they are staged
+template <bool FUSE>
 __global__ __launch_bounds__(NT) void wgrad_stem_kernel(const StemWgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -65,9 +69,11 @@ __global__ __launch_bounds__(NT) void wgrad_stem_kernel(const StemWgArgs a) {
   }
   const int doff = kpx * DSTRIDE + 8 * p;            // A operand (dY): + 32 bytes per 16-channel row tile
 
-  u32x4 xr[XITEMS], dr[DITEMS];
+  u32x4 xr[XITEMS], dr[DITEMS], yr[FUSE ? DITEMS : 1];
+  unsigned dr_tok = 0u;
   auto load_tile = [&](int tile) {
     const bool tok = tile < a.ntiles;
+    dr_tok = tok ? 1u : 0u;
     const int tl = tok ? tile : 0;
     const int n = tl / (tiles_x * tiles_y);
     const int trem = tl - n * tiles_x * tiles_y;
@@ -90,6 +96,7 @@ __global__ __launch_bounds__(NT) void wgrad_stem_kernel(const StemWgArgs a) {
       const unsigned off = (unsigned)(((n * H + y0 + py) * W + x0 + pxx) * 64 + ch * 8);
       const u32x4 v = *reinterpret_cast<const u32x4*>(a.dy + (tok ? off : 0u));
       dr[k] = tok ? v : u32x4{0u, 0u, 0u, 0u};
+      if constexpr (FUSE) yr[k] = *reinterpret_cast<const u32x4*>(a.y + (tok ? off : 0u));
     }
   };
   auto store_tile = [&](int buf) {
@@ -100,10 +107,33 @@ __global__ __launch_bounds__(NT) void wgrad_stem_kernel(const StemWgArgs a) {
       const int it = t + NT * k;
       if (it < HPIX) *reinterpret_cast<u32x4*>(xh + it * XSTRIDE) = xr[k];
     }
+    float k1[8], k2[8], k3[8], sc[8], sh[8];
+    if constexpr (FUSE) {   // this thread's channel chunk (t & 7) never changes; re-read per tile (L1) rather than held
+      const int c0 = (t & 7) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        k1[e] = a.coef[c0 + e]; k2[e] = a.coef[64 + c0 + e]; k3[e] = a.coef[128 + c0 + e];
+        sc[e] = a.msc[c0 + e]; sh[e] = a.msh[c0 + e];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < DITEMS; ++k) {
       const int it = t + NT * k;
-      *reinterpret_cast<u32x4*>(dyt + (it >> 3) * DSTRIDE + (it & 7) * 16) = dr[k];
+      u32x4 v = dr[k];
+      if constexpr (FUSE) {
+        float d[8], yy[8], g[8];
+        chunk_to_f<bf16_t>(__builtin_bit_cast(uint4, dr[k]), d);
+        chunk_to_f<bf16_t>(__builtin_bit_cast(uint4, yr[k]), yy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dm = fmaf(yy[e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
+          g[e] = fmaf(k1[e], dm, fmaf(k2[e], yy[e], k3[e]));
+        }
+        v = __builtin_bit_cast(u32x4, f_to_chunk<bf16_t>(g));
+        // (tiles past the end: dz = 0 but k2*y + k3 is not — mask the whole chunk)
+        if (dr_tok == 0u) v = u32x4{0u, 0u, 0u, 0u};
+      }
+      *reinterpret_cast<u32x4*>(dyt + (it >> 3) * DSTRIDE + (it & 7) * 16) = v;
     }
   };
   typedef __attribute__((address_space(3))) s16x4_t* lds_p;
@@ -176,21 +206,27 @@ static int stem_splits(const WgradArgs& a) {
 
 size_t wgrad_stem_workspace_bytes(const WgradArgs& a) { return (size_t)stem_splits(a) * 64 * TAPS * 8 * sizeof(float); }
 
+bool wgrad_bnapply_fusable(int dtype, const WgradArgs& a) { return tune("FLAIR_STEM_FUSE", 1) && wgrad_stem_applicable(dtype, a); }
+
 int launch_wgrad_stem(const WgradArgs& a, hipStream_t s) {
   StemWgArgs h;
   h.x = (const bf16_t*)a.x0; h.dy = (const bf16_t*)a.dy; h.partial = a.partial;
   h.N = a.N; h.H = a.Hout; h.W = a.Wout; h.ntiles = (int)((long)a.N * a.Hout * a.Wout / TPIX);
+  h.y = (const bf16_t*)a.fuse_y; h.coef = a.fuse_coef; h.msc = a.fuse_msc; h.msh = a.fuse_msh;
+  if (h.y && (!h.coef || !h.msc || !h.msh)) return -2;
   const int nsplit = stem_splits(a);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_stem_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_stem_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   {
     const double M = (double)a.N * a.Hout * a.Wout;
-    ProfScope ps("wgrad_stem_bf16", 2.0 * M * 64 * TAPS * 8, (M * 64 + 4.0 * M * 8) * 2.0, s);
-    hipLaunchKernelGGL(wgrad_stem_kernel, dim3(nsplit), dim3(NT), SMEM, s, h);
+    ProfScope ps("wgrad_stem_bf16", 2.0 * M * 64 * TAPS * 8, (M * 64 * (h.y ? 2 : 1) + 4.0 * M * 8) * 2.0, s);
+    if (h.y) hipLaunchKernelGGL(wgrad_stem_kernel<true>, dim3(nsplit), dim3(NT), SMEM, s, h);
+    else hipLaunchKernelGGL(wgrad_stem_kernel<false>, dim3(nsplit), dim3(NT), SMEM, s, h);
   }
   FLAIR_CHECK_LAUNCH();
   launch_wgrad_reduce(a.partial, a.dw, nsplit, 64, 64, TAPS * 8, 8, a.Cin_real, 7, 7, a.accumulate, s);

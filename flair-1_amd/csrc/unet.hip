@@ -598,16 +598,20 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
   // ReLU mask: units without a residual recompute it from y (out > 0 <=> y*scale + shift > 0) and skip
   // reading the activation tensor in both backward passes
   const bool mask_from_y = u.relu && u.res_unit < 0 && !u.res.p;
-  RUN(bn_backward(dtype, dout, (u.relu && !mask_from_y) ? u.out.p : nullptr, u.y.p, u.mean, u.invstd, params_ + b.g_off,
-                  rows, b.C, partial, coef, grads_ + b.g_off, grads_ + b.b_off, 0, dy, dres, dres_acc ? 1 : 0,
-                  mask_from_y ? u.scale : nullptr, mask_from_y ? u.shift : nullptr, pre_nblk, s_));
-  // weight gradient
+  // weight gradient (described first: a unit without a data gradient may fold the BatchNorm-backward apply into it)
   WgradArgs w;
   memset(&w, 0, sizeof(w));
   w.x0 = u.in0.p; w.x1 = u.in1.p; w.C0 = u.in0.C; w.C1 = u.in1.p ? u.in1.C : 0; w.up0 = u.up0 ? 1 : 0;
   w.N = u.in0.N; w.Hin = u.up0 ? u.in0.H * 2 : u.in0.H; w.Win = u.up0 ? u.in0.W * 2 : u.in0.W;
   w.Hout = u.y.H; w.Wout = u.y.W; w.R = c.R; w.S = c.S; w.stride = c.stride; w.pad = c.pad;
   w.dy = dy; w.dy_ld = u.y.C; w.Cout = c.Cout;
+  // the stem: dy feeds nothing but the weight gradient, whose kernel stages it chunk by chunk — it applies the affine itself and
+  // the tensor is never written (bn_bwd_apply: 804 MB of traffic for a 268 MB operand read once)
+  const bool fuse_apply = !need_dgrad && !dres && mask_from_y && wgrad_bnapply_fusable(dtype, w);
+  RUN(bn_backward(dtype, dout, (u.relu && !mask_from_y) ? u.out.p : nullptr, u.y.p, u.mean, u.invstd, params_ + b.g_off,
+                  rows, b.C, partial, coef, grads_ + b.g_off, grads_ + b.b_off, 0, fuse_apply ? nullptr : dy, dres, dres_acc ? 1 : 0,
+                  mask_from_y ? u.scale : nullptr, mask_from_y ? u.shift : nullptr, pre_nblk, s_));
+  if (fuse_apply) { w.dy = dout; w.fuse_y = u.y.p; w.fuse_coef = coef; w.fuse_msc = u.scale; w.fuse_msh = u.shift; }
   w.dw = grads_ + c.w_off; w.Cin_real = c.Cin; w.accumulate = 0;
   w.in_scale = u.in0.lz_scale; w.in_shift = u.in0.lz_shift;
   w.cus = side_cus(ui);

@@ -344,6 +344,7 @@ int launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if ((a.C0 % ch) || (a.C1 % ch) || (a.dy_ld % ch)) return -2;
   if (a.dbias) return wgrad_dbias_fusable(dtype, a) ? launch_wgrad_halo(dtype, a, s) : -6;
+  if (a.fuse_y && !wgrad_stem_applicable(dtype, a)) return -6;
   if (a.in_scale) {   // lazy input: the two halo-staging kernels apply it
     if (wgrad_big_applicable(dtype, a)) return launch_wgrad_big(dtype, a, s);
     return wgrad_halo_applicable(a) ? launch_wgrad_halo(dtype, a, s) : -6;
