@@ -63,10 +63,19 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out
   }
 }
 
+// bnr_*: optional first pass of the BatchNorm backward of the unit whose ReLU output this gradient belongs to (the stem): the
+// kernel completes that gradient, so it also leaves sum(dz*m), sum(dz*m*y), m = [y*msc + msh > 0], per workgroup in
+// bnr_partial[2][C][gridDim.x] — what bn_bwd_reduce_kernel would re-read the 268 MB tensor for.
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ idx,
-                                   T* __restrict__ din, int accumulate, int N, int H, int W, int C) {
+                                   T* __restrict__ din, int accumulate, int N, int H, int W, int C,
+                                   const T* __restrict__ bnr_y, const float* __restrict__ bnr_msc, const float* __restrict__ bnr_msh,
+                                   float* __restrict__ bnr_partial) {
   constexpr int CH = Elem<T>::CH;
+  __shared__ float bsh[256 * 2 * CH];
+  float r1[CH], r2[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { r1[e] = 0.f; r2[e] = 0.f; }
   const int Ho = H / 2, Wo = W / 2, cpr = C / CH;
   const int h = blockIdx.x % H, n = blockIdx.x / H;   // one workgroup per input row, 32-bit index arithmetic
   const unsigned row_items = (unsigned)W * cpr;
@@ -105,7 +114,32 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dout, const unsigned ch
           if (ti[e] == tap) g[e] += d[e];
       }
     }
-    *reinterpret_cast<uint4*>(din + i * CH) = f_to_chunk<T>(g);
+    const uint4 gv = f_to_chunk<T>(g);
+    *reinterpret_cast<uint4*>(din + i * CH) = gv;
+    if (bnr_partial) {   // a thread keeps its channel chunk cx (blockDim.x % cpr == 0)
+      float d[CH], yy[CH];
+      chunk_to_f<T>(gv, d);
+      chunk_to_f<T>(*reinterpret_cast<const uint4*>(bnr_y + i * CH), yy);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const float dm = fmaf(yy[e], bnr_msc[cx * CH + e], bnr_msh[cx * CH + e]) > 0.f ? d[e] : 0.f;
+        r1[e] += dm;
+        r2[e] = fmaf(dm, yy[e], r2[e]);
+      }
+    }
+  }
+  if (bnr_partial) {   // fixed-order sum over the threads of a chunk column
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { bsh[(t * 2) * CH + e] = r1[e]; bsh[(t * 2 + 1) * CH + e] = r2[e]; }
+    __syncthreads();
+    if (t < C) {
+      const int cx = t / CH, e = t - cx * CH;
+      float x1 = 0.f, x2 = 0.f;
+      for (int th = cx; th < (int)blockDim.x; th += cpr) { x1 += bsh[(th * 2) * CH + e]; x2 += bsh[(th * 2 + 1) * CH + e]; }
+      bnr_partial[(long)t * gridDim.x + blockIdx.x] = x1;
+      bnr_partial[((long)C + t) * gridDim.x + blockIdx.x] = x2;
+    }
   }
 }
 
@@ -402,14 +436,18 @@ int maxpool3x3s2_fwd(int dtype, const void* in, void* out, unsigned char* idx, i
 }
 
 int maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, void* din, int accumulate, int N, int H,
-                     int W, int C, hipStream_t s) {
+                     int W, int C, hipStream_t s, const void* bnr_y, const float* bnr_msc, const float* bnr_msh,
+                     float* bnr_partial) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C % ch || (H & 1) || (W & 1)) return -2;
+  if (bnr_partial && (C > 256 || 256 % (C / ch) || !bnr_y || !bnr_msc || !bnr_msh)) return -2;
   ProfScope ps("maxpool_bwd", 0.0, (double)N * H * W * C * (dtype_size(dtype) * (1.25 + accumulate) + 0.25), s);
   if (dtype == DT_F32)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(N * H), dim3(256), 0, s, (const float*)dout, idx, (float*)din, accumulate, N, H, W, C);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(N * H), dim3(256), 0, s, (const float*)dout, idx, (float*)din, accumulate, N, H, W, C,
+                       (const float*)bnr_y, bnr_msc, bnr_msh, bnr_partial);
   else
-    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(N * H), dim3(256), 0, s, (const bf16_t*)dout, idx, (bf16_t*)din, accumulate, N, H, W, C);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(N * H), dim3(256), 0, s, (const bf16_t*)dout, idx, (bf16_t*)din, accumulate, N, H, W, C,
+                       (const bf16_t*)bnr_y, bnr_msc, bnr_msh, bnr_partial);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }

@@ -25,7 +25,8 @@ int colsum(int dtype, const void* x, long rows, int ld, int C, float* partial, f
 // ---- misc.hip
 int maxpool3x3s2_fwd(int dtype, const void* in, void* out, unsigned char* idx, int N, int H, int W, int C, hipStream_t s);
 int maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, void* din, int accumulate, int N, int H,
-                     int W, int C, hipStream_t s);
+                     int W, int C, hipStream_t s, const void* bnr_y = nullptr, const float* bnr_msc = nullptr,
+                     const float* bnr_msh = nullptr, float* bnr_partial = nullptr);   // bnr_*: fused BN-backward reduction, [2][C][N*H] partials
 int upcat_bwd(int dtype, const void* dcat, void* dx0, int dx0_accumulate, void* dskip, int dskip_accumulate, int N,
               int H, int W, int C0, int C1, hipStream_t s);
 int nchw_f32_to_nhwc(int dtype, const float* in, void* out, int N, int C, int H, int W, int Cp, hipStream_t s);

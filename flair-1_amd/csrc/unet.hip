@@ -753,7 +753,17 @@ void UNet::encoder_bwd_impl() {
   // maxpool: d f1 (+)= scatter(d pool)
   bool acc = false;
   void* df1 = grad_of(f_[1], &acc);
-  RUN(maxpool3x3s2_bwd(dtype, grad_peek(pool_), pool_idx_, df1, acc ? 1 : 0, B_, f_[1].H, f_[1].W, 64, s_));
+  {
+    // the max-pool backward completes the gradient of the stem's ReLU output: it also runs the first pass of the stem's
+    // BatchNorm backward on it (mask from y; the stem has no residual)
+    Unit& u0 = units_[0];
+    const bool fuse = tune("FLAIR_POOL_BNR", 1) && u0.relu && u0.res_unit < 0 && !u0.res.p && u0.y.C == 64;
+    float* part = nullptr;
+    const int nblk = B_ * f_[1].H;
+    if (fuse) { part = alloc_f((long)nblk * 2 * u0.y.C); u0.bnr_partial = part; u0.bnr_nblk = nblk; }
+    RUN(maxpool3x3s2_bwd(dtype, grad_peek(pool_), pool_idx_, df1, acc ? 1 : 0, B_, f_[1].H, f_[1].W, 64, s_,
+                         fuse ? u0.y.p : nullptr, fuse ? u0.scale : nullptr, fuse ? u0.shift : nullptr, part));
+  }
   unit_backward(0, df1, nullptr, false, false, nullptr);  // stem: no data gradient
   stage_done(0);
 }
