@@ -143,10 +143,13 @@ bool UNet::side_init() {
   const hipError_t ce = low ? hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, least)
                             : hipStreamCreateWithFlags(&side_, hipStreamNonBlocking);
   if (ce != hipSuccess) { side_ = nullptr; return false; }
+  // The fork / join events order streams of ONE device: no system-scope fence (the default makes every record write back and
+  // invalidate the caches — 50 times per step, in front of the kernels that re-read what was just written)
+  const unsigned evflags = hipEventDisableTiming | (tune("FLAIR_EVENT_SYSFENCE", 0) ? 0u : hipEventDisableSystemFence);
   fork_ev_.resize(128);
   for (auto& e : fork_ev_)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
-  return hipEventCreateWithFlags(&join_ev_, hipEventDisableTiming) == hipSuccess;
+    if (hipEventCreateWithFlags(&e, evflags) != hipSuccess) return false;
+  return hipEventCreateWithFlags(&join_ev_, evflags) == hipSuccess;
 }
 
 // Space sharing instead of time sharing: on the side stream the persistent weight-gradient kernel takes only HALF of the

@@ -11,6 +11,8 @@ BatchNorm statistics stay per rank (no SyncBN), like the reference.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -72,6 +74,8 @@ class SegTrainer:
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         # rehearsal switch: run the event / side-stream / RCCL exchange even with one rank (1-GPU test boxes)
         self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
+        self._no_collective = self.world == 1 and os.environ.get("FLAIR_REHEARSE_NO_COLLECTIVE") == "1"
+
         self.overlap = overlap
         p = model.flat_parameters()
         dev = p.device
@@ -131,6 +135,8 @@ class SegTrainer:
             with torch.cuda.stream(self.comm_stream):
                 for (b, e), st in zip(self.buckets, self._bucket_stage):
                     self.comm_stream.wait_event(self.events[st])
+                    if self._no_collective:   # diagnostic (FLAIR_REHEARSE_NO_COLLECTIVE=1): stage events and waits only
+                        continue
                     works.append(dist.all_reduce(self.grads[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             for w in works:
                 w.wait()
