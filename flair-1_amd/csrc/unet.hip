@@ -780,7 +780,18 @@ void UNet::stage_done(int stage) {
     // The stage's weight gradients live on the side stream, the rest on s_.  Neither stream may wait for the other
     // here (that would serialise the weight-gradient tails behind the data-gradient chain six times per step): a third
     // stream waits for the current position of both and carries the stage event, which fires when both are done.
-    if (!note_ && hipStreamCreateWithFlags(&note_, hipStreamNonBlocking) != hipSuccess) note_ = nullptr;
+    if (!note_) {
+      // LOW priority, like the side stream: a stream of the caller's priority level may share the caller's hardware queue, and its
+      // wait for the side stream's position would then hold back every kernel the caller queues behind it
+      int least = 0, greatest = 0;
+      const int np = tune("FLAIR_NOTE_PRIO", 1);
+      hipError_t ce;
+      if (np && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+        ce = hipStreamCreateWithPriority(&note_, hipStreamNonBlocking, np == 2 ? greatest : least);
+      else
+        ce = hipStreamCreateWithFlags(&note_, hipStreamNonBlocking);
+      if (ce != hipSuccess) note_ = nullptr;
+    }
     if (note_) {
       hipEvent_t e1 = fork_ev_[fork_next_++ % fork_ev_.size()];
       hipEvent_t e2 = fork_ev_[fork_next_++ % fork_ev_.size()];
