@@ -36,7 +36,9 @@ int flair_profile_start(int max_records) {
   if (max_records < 1) return -1;
   while (g_ev.size() < (size_t)2 * max_records) {
     hipEvent_t e;
-    hipError_t rc = hipEventCreate(&e);
+    // timing events without the system-scope fence: the default writes back and invalidates the caches at every record, which
+    // slows the very kernels being timed (hip_runtime_api.h, hipEventDisableSystemFence)
+    hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
     if (rc != hipSuccess) return (int)rc;
     g_ev.push_back(e);
   }
