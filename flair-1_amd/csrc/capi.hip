@@ -63,6 +63,11 @@ int64_t flair_unet_workspace_bytes(flair_unet_t* h, int B, int H, int W, int tra
   return (int64_t)h->net.workspace_bytes(B, H, W, training);
 }
 int flair_unet_head_ld(const flair_unet_t* h) { return h ? h->net.convs.back().Cout_p : -1; }
+int flair_unet_want_preds(flair_unet_t* h, uint8_t* preds_u8) {
+  if (!h) return -1;
+  h->net.want_preds(preds_u8);
+  return 0;
+}
 int flair_unet_reuse_constants(flair_unet_t* h, int on) {
   if (!h) return -1;
   h->net.reuse_constants(on != 0);

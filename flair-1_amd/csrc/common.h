@@ -142,7 +142,12 @@ struct ConvArgs {
   int bnr_C;
   // diagnostic builds only (FLAIR_HG_STAMP): per-workgroup s_memtime stamps [gridDim.x][8], written by thread 0
   unsigned long long* dbg;
+  // optional (persistent small-channel kernel with one column block, conv_halo_preds_ok()): argmax over the Cout output channels
+  // of every pixel, first maximum wins, NaN wins over numbers — what argmax(softmax(logits)) of the reference's predict_step
+  // returns away from exact ties of the rounded probabilities — as uint8 [N][H][W]; `out` may then be null
+  unsigned char* preds_u8;
 };
+bool conv_halo_preds_ok(int dtype, const ConvArgs& a);
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s);
 int conv_grid_rows(int dtype, const ConvArgs& a);  // number of row blocks (= partial-stat rows)

@@ -733,6 +733,12 @@ static int halo_rows_t(const ConvArgs& a) {
 
 bool conv_halo_bnr_applicable(const ConvArgs& a) { return conv_halo_applicable(a) && conv_halo_bnr_ok(a); }
 
+// fused argmax (ConvArgs::preds_u8): the persistent single-block kernel whose column block holds every class
+bool conv_halo_preds_ok(int dtype, const ConvArgs& a) {
+  (void)dtype;
+  return tune("FLAIR_HEAD_ARGMAX", 1) && conv_halo_applicable(a) && halo_persistent(a) && !a.pool_c0 && !a.bnr_partial && a.Cout <= 32;
+}
+
 int conv_halo_grid_rows(int dtype, const ConvArgs& a) {
   if (halo_persistent_multi(dtype, a)) return halo_pm_blocks<bf16_t, 32, 32, 4>(a);
   if (halo_persistent(a)) return dtype == DT_F32 ? halo_rows_t<float>(a) : halo_rows_t<bf16_t>(a);
@@ -742,6 +748,7 @@ int conv_halo_grid_rows(int dtype, const ConvArgs& a) {
 int launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s) {
   const int Cin = a.C0 + a.C1;
   const bool n16 = a.Cout <= 16;
+  if (a.preds_u8 && !conv_halo_preds_ok(dtype, a)) return -6;
   if (halo_persistent_multi(dtype, a))
     return a.in_scale ? launch_halo_pm_l<bf16_t, 32, 32, 4, true>(a, s) : launch_halo_pm_l<bf16_t, 32, 32, 4, false>(a, s);
   if (halo_persistent(a)) {

@@ -398,6 +398,7 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
+  if (a.preds_u8 && !conv_halo_preds_ok(dtype, a)) return -6;   // fused argmax: persistent small-channel kernel only
   if (a.out_sub && (a.out_nchw || a.stats || a.pool_c0 > 0 || a.bnr_partial || conv_hg_applicable(dtype, a) || conv_halo_applicable(a)))
     return -6;  // sub-sampled stores exist in the gather-form epilogue only
   if (a.in_scale) {   // lazy BN + ReLU on the input: the halo-GEMM (>= 64 channels) and the small-channel halo kernel apply it

@@ -134,6 +134,30 @@ __device__ __forceinline__ void direct_store(const ConvArgs& a, const f32x4_t (&
           v[i][e] = Elem<T>::to_f(Elem<T>::from_f(acc[i][q][rr]));
         }
       }
+  if (a.preds_u8) {
+    // argmax over the column block's channels: a lane holds 4*TN consecutive ones of pixel lr, lanes lr + 16*lq the others
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float bv = 0.f; int bi = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < NCH; ++e) {
+        const float x = v[i][e];
+        const bool take = nn + e < a.Cout && (bi == 0x7fffffff || x > bv || (x != x && bv == bv));
+        if (take) { bv = x; bi = nn + e; }
+      }
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        // the other lane's candidate wins if it is larger (NaN counts as larger than any number), or equal with a lower index
+        const bool o_nan = ov != ov, m_nan = bv != bv;
+        const bool take = oi != 0x7fffffff && (bi == 0x7fffffff || (o_nan && !m_nan) || (!m_nan && ov > bv) ||
+                                               ((o_nan == m_nan) && (o_nan || ov == bv) && oi < bi));
+        if (take) { bv = ov; bi = oi; }
+      }
+      if (lq == 0) a.preds_u8[((long)n * H + y0 + 2 * wave + (i >> 1)) * W + x0 + (i & 1) * 16 + lr] = (unsigned char)bi;
+    }
+  }
   if (a.out_nchw) {
     const long HWp = (long)H * W;
 #pragma unroll

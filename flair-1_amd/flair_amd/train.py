@@ -158,10 +158,11 @@ class SegTrainer:
             return self._predict(m, img, B, H, W)
 
     def _predict(self, m, img, B, H, W):
-        m._c_forward(img, training=False, want_logits=False)   # logits stay NHWC in the workspace
         preds = torch.empty(B, H, W, dtype=torch.uint8, device=img.device)
         l = L.lib()
         he = m._hh(False)   # eval forwards run on their own executor
-        L.check(l.flair_softmax_argmax_nhwc(l.flair_unet_logits_nhwc(he), m._dt, l.flair_unet_head_ld(he), B, m.classes, H, W,
-                                            L.ptr(preds), None, None, L.stream()), "softmax_argmax_nhwc")
+        # the argmax comes out of the head convolution's epilogue (or, for shapes its persistent kernel does not take, from the
+        # separate pass over the NHWC logits inside the same native call): the logits never reach HBM
+        L.check(l.flair_unet_want_preds(he, L.ptr(preds)), "flair_unet_want_preds")
+        m._c_forward(img, training=False, want_logits=False)
         return preds

@@ -63,6 +63,10 @@ int flair_unet_head_ld(const flair_unet_t* h);
  * are still in the workspace); any other call clears the promise.  The reference has no counterpart: PyTorch modules keep
  * their weights in the layout they compute in. */
 int flair_unet_reuse_constants(flair_unet_t* h, int on);
+/* One-shot: the next flair_unet_forward with training = 0 and logits = NULL writes uint8 argmax predictions [B][H][W] to preds_u8
+ * (device pointer) — predict_step's argmax(softmax(logits)), task_module.py:206-213 — from the head convolution's epilogue; the
+ * logits are then not kept (flair_unet_logits_nhwc returns NULL until the next forward). */
+int flair_unet_want_preds(flair_unet_t* h, uint8_t* preds_u8);
 
 /* seg_model.encoder(x) / .decoder(*feats) / .segmentation_head(t) — the metadata path model.py:57-62.
  * feats[i] = feature i+1 of the encoder, NCHW fp32: (B,64,H/2,W/2) ... (B,512,H/32,W/32). */
