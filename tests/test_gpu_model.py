@@ -740,3 +740,21 @@ def test_fused_and_persistent_paths_agree_with_the_plain_ones(dev, dtype):
         # biases) move by percents of their own scale.  Direction and the bulk must agree.
         assert worst_cos[0] >= 0.995, worst_cos
         assert worst[0] <= 0.10, worst
+
+
+@pytest.mark.parametrize("dtype,classes", [("f32", 13), ("bf16", 13), ("bf16", 19), ("f32", 19)])
+def test_predict_argmax_from_the_head_epilogue_equals_argmax_of_the_logits(dev, dtype, classes):
+    """SegTrainer.predict takes the argmax out of the head convolution's epilogue (flair_unet_want_preds).  It must equal the
+    first-maximum argmax of the logits the same forward would have returned (fp32 NCHW copy of the same rounded values), for
+    the one-block (13 classes) and the two-block (19 classes) column layouts."""
+    import flair_amd
+    _, m = _pair(5, classes, 23, dev, dtype)
+    m = m.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 5, 96, 160, generator=g).to(dev)
+    tr = flair_amd.SegTrainer(m, lr=0.0)
+    preds = tr.predict(x)
+    logits = m._c_forward(x, training=False, want_logits=True)
+    ref = logits.argmax(dim=1).to(torch.uint8)
+    assert preds.shape == ref.shape and preds.dtype == torch.uint8
+    assert torch.equal(preds, ref), int((preds != ref).sum())
