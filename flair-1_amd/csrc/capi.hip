@@ -63,9 +63,9 @@ int64_t flair_unet_workspace_bytes(flair_unet_t* h, int B, int H, int W, int tra
   return (int64_t)h->net.workspace_bytes(B, H, W, training);
 }
 int flair_unet_head_ld(const flair_unet_t* h) { return h ? h->net.convs.back().Cout_p : -1; }
-int flair_unet_want_preds(flair_unet_t* h, uint8_t* preds_u8) {
-  if (!h) return -1;
-  h->net.want_preds(preds_u8);
+int flair_unet_want_preds(flair_unet_t* h, uint8_t* preds_u8, float* maxprob_f32) {
+  if (!h || (maxprob_f32 && !preds_u8)) return -1;
+  h->net.want_preds(preds_u8, maxprob_f32);
   return 0;
 }
 int flair_unet_reuse_constants(flair_unet_t* h, int on) {
@@ -188,6 +188,11 @@ int flair_detect_stitch(const float* logits_nchw, int B, int C, int S, int margi
                         void* raster_out, int raster_h, int raster_w, void* stream) {
   if (!logits_nchw || !raster_out || !tiles) return -1;
   return detect_convert(logits_nchw, B, C, S, margin, output_type, raster_out, tiles, raster_h, raster_w, (hipStream_t)stream);
+}
+int flair_detect_stitch_preds(const uint8_t* preds_u8, const float* maxprob_f32, int B, int S, int margin, const int32_t* tiles,
+                              float* raster_out, int raster_h, int raster_w, void* stream) {
+  if (!preds_u8 || !maxprob_f32 || !raster_out || !tiles) return -1;
+  return detect_stitch_preds(preds_u8, maxprob_f32, B, S, margin, tiles, raster_out, raster_h, raster_w, (hipStream_t)stream);
 }
 int flair_gather_tiles(const uint8_t* raster_u8, int bands, int raster_h, int raster_w, const int32_t* tiles, int B, int S,
                        const int* channels, int n_channels, int norm_type, const double* means, const double* stds,

@@ -146,6 +146,7 @@ struct ConvArgs {
   // of every pixel, first maximum wins, NaN wins over numbers — what argmax(softmax(logits)) of the reference's predict_step
   // returns away from exact ties of the rounded probabilities — as uint8 [N][H][W]; `out` may then be null
   unsigned char* preds_u8;
+  float* maxprob_f32;   // with preds_u8: the winner's softmax probability, 1 / sum_c exp(x_c - max), fp32 [N][H][W] (convert('argmax') band 1)
 };
 bool conv_halo_preds_ok(int dtype, const ConvArgs& a);
 

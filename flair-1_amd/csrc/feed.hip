@@ -163,6 +163,28 @@ __global__ __launch_bounds__(256) void detect_convert_kernel(const float* __rest
   }
 }
 
+// convert('argmax') from per-window (class, probability) maps that the head convolution left (flair_unet_want_preds): the same
+// ownership windows as detect_convert_kernel, band 0 = class as float32, band 1 = its softmax probability
+__global__ __launch_bounds__(256) void detect_stitch_preds_kernel(const unsigned char* __restrict__ preds, const float* __restrict__ maxprob,
+                                                                  int B, int S, int margin, const int* __restrict__ tiles,
+                                                                  float* __restrict__ out, int Hr, int Wr) {
+  const int K = S - 2 * margin;
+  const long KK = (long)K * K, SS = (long)S * S, total = KK * B;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(t / KK);
+    const long r = t - (long)b * KK;
+    const int i = (int)(r / K), j = (int)(r - (long)i * K);
+    const int* tb = tiles + b * 6;
+    const int gx = tb[0] + margin + j, gy = tb[1] + margin + i;
+    if (gx < tb[2] || gx >= tb[3] || gy < tb[4] || gy >= tb[5]) continue;
+    if ((unsigned)gx >= (unsigned)Wr || (unsigned)gy >= (unsigned)Hr) continue;
+    const long src = (long)b * SS + (long)(i + margin) * S + (j + margin);
+    const long dst = (long)gy * Wr + gx;
+    out[dst] = (float)preds[src];
+    out[(long)Hr * Wr + dst] = maxprob[src];
+  }
+}
+
 __global__ __launch_bounds__(256) void confmat_masks_kernel(const unsigned char* __restrict__ truth, const unsigned char* __restrict__ pred,
                                                             long n, int C, int truth_offset, long long* __restrict__ confmat) {
   __shared__ unsigned int hist[MAXC * MAXC];
@@ -222,6 +244,17 @@ int detect_convert(const float* logits, int B, int C, int S, int margin, int mod
   ProfScope ps(tiles ? "detect_stitch" : "detect_convert", 0.0, (double)B * K * K * (4.0 * C + (mode == 2 ? 4.0 * C : mode ? C : 8.0)), s);
   hipLaunchKernelGGL(detect_convert_kernel, dim3(stream_blocks((long)B * K * K)), dim3(256), 0, s, logits, B, C, S, margin, mode, out,
                      tiles, Hr, Wr);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int detect_stitch_preds(const unsigned char* preds, const float* maxprob, int B, int S, int margin, const int* tiles, float* out,
+                        int Hr, int Wr, hipStream_t s) {
+  if (B < 1 || margin < 0 || S - 2 * margin < 1 || Hr < 1 || Wr < 1) return -2;
+  const long K = S - 2 * margin;
+  ProfScope ps("detect_stitch", 0.0, (double)B * K * K * (5.0 + 8.0), s);
+  hipLaunchKernelGGL(detect_stitch_preds_kernel, dim3(stream_blocks((long)B * K * K)), dim3(256), 0, s, preds, maxprob, B, S, margin, tiles,
+                     out, Hr, Wr);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }

@@ -99,6 +99,8 @@ struct FeedArgs {
 };
 int feed_tiles(const FeedArgs& a, hipStream_t s);
 int gather_tiles(const FeedArgs& a, const int* tiles, int Hr, int Wr, hipStream_t s);  // a.img: one (Cb, Hr, Wr) raster
+int detect_stitch_preds(const unsigned char* preds, const float* maxprob, int B, int S, int margin, const int* tiles, float* out,
+                        int Hr, int Wr, hipStream_t s);
 int detect_convert(const float* logits, int B, int C, int S, int margin, int mode, void* out, const int* tiles, int Hr, int Wr,
                    hipStream_t s);
 int confmat_masks(const unsigned char* truth, const unsigned char* pred, long n, int C, int truth_offset, long long* confmat,

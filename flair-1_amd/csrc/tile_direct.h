@@ -155,7 +155,17 @@ __device__ __forceinline__ void direct_store(const ConvArgs& a, const f32x4_t (&
                                                ((o_nan == m_nan) && (o_nan || ov == bv) && oi < bi));
         if (take) { bv = ov; bi = oi; }
       }
-      if (lq == 0) a.preds_u8[((long)n * H + y0 + 2 * wave + (i >> 1)) * W + x0 + (i & 1) * 16 + lr] = (unsigned char)bi;
+      const long pix = ((long)n * H + y0 + 2 * wave + (i >> 1)) * W + x0 + (i & 1) * 16 + lr;
+      if (lq == 0) a.preds_u8[pix] = (unsigned char)bi;
+      if (a.maxprob_f32) {   // softmax probability of the winner: exp(0) / sum_c exp(x_c - max)
+        float ssum = 0.f;
+#pragma unroll
+        for (int e = 0; e < NCH; ++e)
+          if (nn + e < a.Cout) ssum += __expf(v[i][e] - bv);   // (2e-7 relative per term; the reference tolerance on this band is 1e-6)
+        ssum += __shfl_xor(ssum, 16);
+        ssum += __shfl_xor(ssum, 32);
+        if (lq == 0) a.maxprob_f32[pix] = 1.f / ssum;
+      }
     }
   }
   if (a.out_nchw) {

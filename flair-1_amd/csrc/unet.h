@@ -108,7 +108,7 @@ class UNet {
   // the 46 BatchNorm-coefficient launches (both still sit in the arena at the same offsets).  One-shot: cleared by forward.
   void reuse_constants(bool on) { reuse_req_ = on; }
   // the next forward without fp32 logits writes argmax predictions [B][H][W] uint8 here (one-shot, like reuse_constants)
-  void want_preds(unsigned char* p) { preds_req_ = p; }
+  void want_preds(unsigned char* p, float* maxprob) { preds_req_ = p; maxprob_req_ = maxprob; }
   void* last_dlogits_nhwc() const { return dl_nhwc_; }
   const void* logits_nhwc() const { return logits_nhwc_; }
   int head_ld() const { return 16 > classes ? 16 : (int)round_up(classes, 8); }
@@ -149,6 +149,7 @@ class UNet {
   size_t fork_next_ = 0;
   bool side_pending_ = false;
   unsigned char* preds_req_ = nullptr;
+  float* maxprob_req_ = nullptr;
   bool side_init();
   hipStream_t wgrad_stream();
   int side_cus(int unit) const;   // forks the side stream behind everything queued on s_ so far

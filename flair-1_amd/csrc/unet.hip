@@ -453,12 +453,13 @@ void UNet::head_fwd_impl(float* logits_nchw) {
   }
   a.bias = params_ + c.b_off;
   unsigned char* preds = (!logits_nchw && !training_) ? preds_req_ : nullptr;
-  preds_req_ = nullptr;
+  float* maxprob = preds ? maxprob_req_ : nullptr;
+  preds_req_ = nullptr; maxprob_req_ = nullptr;
   if (preds && !dry_) {
     // predict: argmax in the head convolution's register epilogue, the logits never reach HBM (536 MB of traffic and the
     // softmax_argmax launch saved); otherwise the separate kernel over the NHWC logits
     ConvArgs b = a;
-    b.out = nullptr; b.preds_u8 = preds;
+    b.out = nullptr; b.preds_u8 = preds; b.maxprob_f32 = maxprob;
     if (conv_halo_preds_ok(dtype, b)) {
       logits_nhwc_ = nullptr;
       RUN(launch_conv(dtype, b, s_));
@@ -467,7 +468,7 @@ void UNet::head_fwd_impl(float* logits_nchw) {
   }
   RUN(launch_conv(dtype, a, s_));
   if (preds && !dry_)
-    RUN(softmax_argmax_nhwc(logits_nhwc_, dtype, c.Cout_p, dec_out_.rows(), c.Cout, preds, nullptr, nullptr, s_));
+    RUN(softmax_argmax_nhwc(logits_nhwc_, dtype, c.Cout_p, dec_out_.rows(), c.Cout, preds, nullptr, maxprob, s_));
 }
 
 int UNet::forward(const float* params, float* buffers, const float* x_nchw, float* logits_nchw, int B, int H, int W,

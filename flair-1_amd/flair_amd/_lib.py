@@ -73,7 +73,8 @@ PROTOTYPES = {
     "flair_metadata_mlp_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "flair_metadata_mlp_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "flair_unet_reuse_constants": (i32, [vp, i32]),
-    "flair_unet_want_preds": (i32, [vp, vp]),
+    "flair_unet_want_preds": (i32, [vp, vp, vp]),
+    "flair_detect_stitch_preds": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp]),
     "flair_tune_set": (i32, [C.c_char_p, i32]),
     "flair_debug_buffer": (i32, [vp]),
 }

@@ -607,6 +607,20 @@ class Unet(nn.Module):
         finally:
             self.train(was)
 
+    @torch.no_grad()
+    @_on_model_device
+    def predict_classes(self, x, want_prob=False):
+        """Eval-mode forward whose head convolution returns the argmax class per pixel (uint8 (B,H,W)) and, with ``want_prob``,
+        that class's softmax probability (fp32 (B,H,W)) from its epilogue — what ``convert(softmax(model(x)), 'argmax')`` of
+        zone_detect (dataset.py:23-30) and ``predict_step`` (task_module.py:206-213) compute — without writing the logits."""
+        x = self._prep(x)
+        B, _, H, W = x.shape
+        preds = torch.empty(B, H, W, dtype=torch.uint8, device=x.device)
+        prob = torch.empty(B, H, W, dtype=torch.float32, device=x.device) if want_prob else None
+        L.check(L.lib().flair_unet_want_preds(self._hh(False), L.ptr(preds), L.ptr(prob)), "flair_unet_want_preds")
+        self._c_forward(x, training=False, want_logits=False)
+        return (preds, prob) if want_prob else preds
+
     def __del__(self):
         try:
             for k in ("_h", "_h_eval"):

@@ -156,6 +156,14 @@ class ZoneDetector:
             L.check(L.lib().flair_gather_tiles(L.ptr(raster_u8), bands, Hr, Wr, L.ptr(tiles), B, self.S, self._ch,
                                                len(self.channels), NORM_CODES[self.norm_type], self._means, self._stds,
                                                L.ptr(imgs), L.stream()), "flair_gather_tiles")
+            if mode == 0 and hasattr(self.model, "predict_classes") and not self.model.training:
+                # 'argmax' output: class and probability leave the head convolution's epilogue, the logits are never written
+                if getattr(self.model, "classes", self.n_classes) != self.n_classes:
+                    raise RuntimeError(f"model has {self.model.classes} classes, config says {self.n_classes}")
+                preds, prob = self.model.predict_classes(imgs, want_prob=True)
+                L.check(L.lib().flair_detect_stitch_preds(L.ptr(preds), L.ptr(prob), B, self.S, self.margin, L.ptr(tiles), L.ptr(out),
+                                                          Hr, Wr, L.stream()), "flair_detect_stitch_preds")
+                continue
             logits = self.model(imgs).float().contiguous()
             if logits.shape[1] != self.n_classes:
                 raise RuntimeError(f"model returned {logits.shape[1]} classes, config says {self.n_classes}")

@@ -66,7 +66,7 @@ int flair_unet_reuse_constants(flair_unet_t* h, int on);
 /* One-shot: the next flair_unet_forward with training = 0 and logits = NULL writes uint8 argmax predictions [B][H][W] to preds_u8
  * (device pointer) — predict_step's argmax(softmax(logits)), task_module.py:206-213 — from the head convolution's epilogue; the
  * logits are then not kept (flair_unet_logits_nhwc returns NULL until the next forward). */
-int flair_unet_want_preds(flair_unet_t* h, uint8_t* preds_u8);
+int flair_unet_want_preds(flair_unet_t* h, uint8_t* preds_u8, float* maxprob_f32 /* optional: the winner's softmax probability */);
 
 /* seg_model.encoder(x) / .decoder(*feats) / .segmentation_head(t) — the metadata path model.py:57-62.
  * feats[i] = feature i+1 of the encoder, NCHW fp32: (B,64,H/2,W/2) ... (B,512,H/32,W/32). */
@@ -163,6 +163,10 @@ int flair_detect_convert(const float* logits_nchw, int B, int C, int S, int marg
 int flair_gather_tiles(const uint8_t* raster_u8, int bands, int raster_h, int raster_w, const int32_t* tiles, int B, int S,
                        const int* channels, int n_channels, int norm_type, const double* means, const double* stds,
                        float* img_out, void* stream);
+/* flair_detect_stitch_preds: convert('argmax') + stitch (dataset.py:23-30, main.py:404-421) from the per-window class / probability maps
+ * flair_unet_want_preds leaves, instead of from logits: raster_out (2, raster_h, raster_w) fp32 = [class, its softmax probability]. */
+int flair_detect_stitch_preds(const uint8_t* preds_u8, const float* maxprob_f32, int B, int S, int margin, const int32_t* tiles,
+                              float* raster_out, int raster_h, int raster_w, void* stream);
 int flair_detect_stitch(const float* logits_nchw, int B, int C, int S, int margin, int output_type, const int32_t* tiles,
                         void* raster_out, int raster_h, int raster_w, void* stream);
 
