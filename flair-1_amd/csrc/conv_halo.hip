@@ -40,7 +40,11 @@ struct HaloCfg {
   static constexpr int CH = Elem<T>::CH;
   static constexpr int KF = 4 * CH;                       // K elements consumed per fragment read
   static constexpr int CPP = CK / CH;                     // 16-byte chunks per halo pixel
-  static constexpr int PSTRIDE = CK * (int)sizeof(T) + ((CK * (int)sizeof(T)) >= 64 ? 16 : 0);  // bytes (odd multiple of 16: no bank conflicts)
+  // bytes per halo pixel.  64-byte pixels get 96: a ds_read_b128 serves 16 lanes = 16 consecutive pixels, eight of them with the
+  // k-chunk of lane group lq and eight with lq ^ 1, and 24-dword strides put the first eight on the multiples of 8 and the others on
+  // 8k + 4 — no two on a bank.  (With 80 bytes three lane pairs of every read collided: SQ_LDS_BANK_CONFLICT was half of the LDS
+  // cycles of the 32-channel kernels; 32 -> 16 at 512^2 190 -> 180 us in same-box pairs.)
+  static constexpr int PSTRIDE = CK * (int)sizeof(T) == 64 ? 96 : CK * (int)sizeof(T) + ((CK * (int)sizeof(T)) >= 64 ? 16 : 0);
   static constexpr int HALO = HPIX * PSTRIDE;
   static constexpr int KW = (9 * CK + KF - 1) / KF * KF;  // weight row length in LDS (zero padded)
   static constexpr int WROW = KW * (int)sizeof(T) + 16;   // bytes, padded against bank conflicts
