@@ -380,14 +380,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < Cfg::KW / KF; ++j) {
+    auto rdk = [&](u32x4 (&af)[TM], u32x4 (&bfr)[TN], int j) {
       const int k0 = j * KF + lq * CH;
       int tap = k0 / CK;
       const int c = k0 - tap * CK;
       tap = tap > 8 ? 8 : tap;  // padded K: the weights there are zero, any valid address will do
       const int r = tap / 3, s = tap - 3 * r;
-      u32x4 af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int py = 2 * wave + (i >> 1), px = (i & 1) * 16 + lr;
@@ -396,10 +394,41 @@ __global__ __launch_bounds__(256) void conv3x3_halo_p_kernel(const ConvArgs a, i
 #pragma unroll
       for (int q = 0; q < TN; ++q)
         bfr[q] = *reinterpret_cast<const u32x4*>(wl + direct_row_channel<TN>(q, lr) * Cfg::WROW + k0 * (int)sizeof(T));
+    };
+    auto mmk = [&](const u32x4 (&af)[TM], const u32x4 (&bfr)[TN]) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int q = 0; q < TN; ++q) HMma<T>::run(bfr[q], af[i], acc[i][q]);   // weights as A: D = [cout][pixel]
+    };
+    constexpr int NK = Cfg::KW / KF;
+    if constexpr (CK == 16) {
+      // 16-channel layers: fragment reads one K step ahead of the MFMAs in two register sets pinned by scheduling fences (hipcc's
+      // own order read a step's five fragments, drained lgkmcnt, then issued its four MFMAs — five exposed LDS round trips per
+      // tile): 16 -> 16 at 512^2 144 -> 122 us, step -0.07 ms in same-box pairs of two builds; the 32-channel variants (nine
+      // steps, more registers) lost 3 % and keep the plain loop
+      u32x4 afA[TM], bfA[TN], afB[TM], bfB[TN];
+      rdk(afA, bfA, 0);
+#pragma unroll
+      for (int j = 0; j < NK; j += 2) {
+        if (j + 1 < NK) rdk(afB, bfB, j + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mmk(afA, bfA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < NK) {
+          if (j + 2 < NK) rdk(afA, bfA, j + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mmk(afB, bfB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        u32x4 af[TM], bfr[TN];
+        rdk(af, bfr, j);
+        mmk(af, bfr);
+      }
     }
     {
       const int n = tile / (tiles_x * tiles_y);
