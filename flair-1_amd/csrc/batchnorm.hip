@@ -424,10 +424,11 @@ int colsum(int dtype, const void* x, long rows, int ld, int C, float* partial, f
 int bn_backward(int dtype, const void* dout, const void* out, const void* y, const float* mean, const float* invstd,
                 const float* gamma, long rows, int C, float* partial, float* coef /*3*C*/, float* dgamma, float* dbeta,
                 int accumulate_param, void* dy, void* dres, int dres_accumulate, const float* mscale, const float* mshift,
-                int pre_nblk, hipStream_t s) {
+                int pre_nblk, int premasked, hipStream_t s) {
   const int ch = dtype == DT_F32 ? 4 : 8;
   if (C % ch || C / ch > 128) return -2;
-  if (pre_nblk > 0 && !out && !mscale) return -2;   // a producer-side reduction needs a mask source (y or out)
+  if (premasked && pre_nblk <= 0) return -2;
+  if (pre_nblk > 0 && !out && !mscale && !premasked) return -2;   // a producer-side reduction needs a mask source (y or out)
   const int nblk = pre_nblk > 0 ? pre_nblk : bn_bwd_blocks(rows);
   const long rpb = (rows + nblk - 1) / nblk;
   if (pre_nblk <= 0) {

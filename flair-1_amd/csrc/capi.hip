@@ -360,7 +360,7 @@ int flair_bn_relu_backward(int dtype, const void* dout, const void* out, const v
   float* coef = (float*)ar.get(3 * C * 4);
   if (ar.bad) return -100;
   return bn_backward(dtype, dout, relu ? out : nullptr, y, save_mean, save_invstd, gamma, rows, C, partial, coef, dgamma,
-                     dbeta, 0, dy, dres, 0, nullptr, nullptr, 0, (hipStream_t)stream);
+                     dbeta, 0, dy, dres, 0, nullptr, nullptr, 0, 0, (hipStream_t)stream);
 }
 
 int flair_maxpool_forward(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {

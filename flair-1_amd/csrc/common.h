@@ -147,7 +147,24 @@ struct ConvArgs {
   // returns away from exact ties of the rounded probabilities — as uint8 [N][H][W]; `out` may then be null
   unsigned char* preds_u8;
   float* maxprob_f32;   // with preds_u8: the winner's softmax probability, 1 / sum_c exp(x_c - max), fp32 [N][H][W] (convert('argmax') band 1)
+  // optional fused BatchNorm-backward APPLY on the input (halo-GEMM data gradients only; ask conv_bnapply_fusable()).  src0 then
+  // holds dz, the gradient w.r.t. the ReLU output of the unit this data gradient belongs to, ALREADY masked by the ReLU (the kernel
+  // that completed it ran with bnr_mask), ap_y the unit's pre-BN tensor (same shape / row stride) and ap_coef = k1 | k2 | k3
+  // (C0 floats each, bn_bwd_finalize_kernel).  The kernel stages  dy = k1*dz + k2*y + k3  with bn_bwd_apply_kernel's arithmetic
+  // and rounding while it fills its halo — the apply pass is gone — and the workgroups of output-channel block 0 also leave the
+  // interior of every staged chunk in ap_dy ([N][H][W][C0] T, optional) for the unit's weight-gradient kernel.
+  const void* ap_y;
+  const float* ap_coef;
+  void* ap_dy;
+  // accumulate == 1 reads its addend from acc_src instead of `out` when set (halo-GEMM epilogue, plain stores only): the
+  // identity branch of a BasicBlock hands its (masked) gradient over without the copy bn_bwd_apply used to make
+  const void* acc_src;
+  // with bnr_partial: store dz * m (m = the ReLU mask the fused reduction computes anyway) instead of dz, so that the consumers
+  // of this gradient need no mask source (halo-GEMM epilogue only)
+  int bnr_mask;
 };
+bool conv_bnapply_fusable(int dtype, const ConvArgs& a);   // a.ap_y set: will launch_conv run the halo-GEMM kernel that applies it?
+bool conv_acc_src_ok(int dtype, const ConvArgs& a);        // a.acc_src set: does the kernel launch_conv picks honour it?
 bool conv_halo_preds_ok(int dtype, const ConvArgs& a);
 
 int launch_conv(int dtype, const ConvArgs& a, hipStream_t s);

@@ -319,6 +319,8 @@ struct HgdCfg {
   static constexpr int HITEMS = (HPIX * 8 + NT - 1) / NT;
   static constexpr int DPW = BTILE / (1024 * NWAVE);   // LDS-DMA instructions per wave and weight tile
   static constexpr int D = NS - 1;                      // prefetch distance in taps
+  static constexpr int APC = 512;                       // XF_APPLY: most input channels (k1 | k2 | k3 table in LDS behind SMEM)
+  static constexpr int APTAB = 3 * APC * 4;
   static_assert(BTILE % (1024 * NWAVE) == 0, "every wave streams whole 1 KiB pieces");
   static_assert(D >= 1 && D <= 3, "ring depth");
 };
@@ -330,14 +332,26 @@ __device__ __forceinline__ void wait_vm_lgkm0(int n) {
     FLAIR_VM_CASE(1) FLAIR_VM_CASE(2) FLAIR_VM_CASE(3) FLAIR_VM_CASE(4) FLAIR_VM_CASE(5) FLAIR_VM_CASE(6) FLAIR_VM_CASE(7)
     FLAIR_VM_CASE(8) FLAIR_VM_CASE(9) FLAIR_VM_CASE(10) FLAIR_VM_CASE(11) FLAIR_VM_CASE(12) FLAIR_VM_CASE(13)
     FLAIR_VM_CASE(14) FLAIR_VM_CASE(15) FLAIR_VM_CASE(16) FLAIR_VM_CASE(17) FLAIR_VM_CASE(18) FLAIR_VM_CASE(19)
-    FLAIR_VM_CASE(20) FLAIR_VM_CASE(21) FLAIR_VM_CASE(22) FLAIR_VM_CASE(23) FLAIR_VM_CASE(24)
+    FLAIR_VM_CASE(20) FLAIR_VM_CASE(21) FLAIR_VM_CASE(22) FLAIR_VM_CASE(23) FLAIR_VM_CASE(24) FLAIR_VM_CASE(25)
+    FLAIR_VM_CASE(26) FLAIR_VM_CASE(27) FLAIR_VM_CASE(28) FLAIR_VM_CASE(29) FLAIR_VM_CASE(30) FLAIR_VM_CASE(31)
+    FLAIR_VM_CASE(32) FLAIR_VM_CASE(33) FLAIR_VM_CASE(34) FLAIR_VM_CASE(35) FLAIR_VM_CASE(36) FLAIR_VM_CASE(37)
+    FLAIR_VM_CASE(38) FLAIR_VM_CASE(39) FLAIR_VM_CASE(40) FLAIR_VM_CASE(41) FLAIR_VM_CASE(42) FLAIR_VM_CASE(43)
+    FLAIR_VM_CASE(44) FLAIR_VM_CASE(45) FLAIR_VM_CASE(46) FLAIR_VM_CASE(47) FLAIR_VM_CASE(48)
     default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
   }
 #undef FLAIR_VM_CASE
 }
 
-template <typename T, int TW, int TH, int BN, int HB, int NS, bool BNR, bool LAZY>
+// XF: transform applied to the input while the halo is staged.  XF_LAZY: BatchNorm + ReLU of the producing unit
+// (ConvArgs::in_scale).  XF_APPLY: the BatchNorm-backward apply dy = k1*dz + k2*y + k3 of the unit this data gradient belongs to
+// (ConvArgs::ap_*): two tensors are read per chunk, and the workgroups of output-channel block 0 write the interior of the
+// transformed chunk back to HBM for the weight-gradient kernel — bn_bwd_apply (45 launches, 155 MB each) is gone for these units.
+enum { XF_NONE = 0, XF_LAZY = 1, XF_APPLY = 2 };
+
+template <typename T, int TW, int TH, int BN, int HB, int NS, bool BNR, int XF>
 __global__ __launch_bounds__(TW * TH * (BN >= 64 ? BN : 64) / 64, 2) void conv3x3_hgd_kernel(const ConvArgs a) {
+  constexpr bool LAZY = XF == XF_LAZY, APPLY = XF == XF_APPLY;
+  static_assert(!APPLY || HB == 1, "the apply flavour is written for the single halo buffer");
   using Cfg = HgdCfg<T, TW, TH, BN, HB, NS>;
   constexpr int CH = Cfg::CH, CK = Cfg::CK, HW_ = Cfg::HW_, HPIX = Cfg::HPIX, NT = Cfg::NT, TPIX = Cfg::TPIX;
   constexpr int TM = 4, TN = Cfg::TN, MTX = TW / 16, DPW = Cfg::DPW, D = Cfg::D, HITEMS = Cfg::HITEMS;
@@ -372,9 +386,13 @@ __global__ __launch_bounds__(TW * TH * (BN >= 64 ? BN : 64) / 64, 2) void conv3x
 
   // ---- halo chunk: global -> registers (one chunk ahead), registers -> [lazy BN + ReLU] -> LDS
   u32x4 hreg[HITEMS];
+  u32x4 yreg[APPLY ? HITEMS : 1];   // XF_APPLY: the pre-BN tensor at the same places
   unsigned hbits = 0;
   float lsc[CH], lsh[CH];
   bool hlazy = false;
+  // XF_APPLY: does this workgroup write the transformed chunks back (output-channel block 0, and somebody wants them)?
+  const bool ap_writer = APPLY && a.ap_dy != nullptr && n0 == 0;
+  int ap_coff = 0;                  // channel offset of the chunk held in hreg / yreg
   auto halo_load = [&](int chunk) {
     const int cbase = chunk * CK;
     const bool use0 = cbase < a.C0;
@@ -392,9 +410,11 @@ __global__ __launch_bounds__(TW * TH * (BN >= 64 ? BN : 64) / 64, 2) void conv3x
       const bool ok = (it < HPIX * 8) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
       const unsigned off = ok ? (unsigned)(((n * Hs + (iy >> sh)) * Ws + (ix >> sh)) * Cs + coff + ch * CH) : 0u;
       hreg[k] = *reinterpret_cast<const u32x4*>(base + off);
+      if constexpr (APPLY) yreg[k] = *reinterpret_cast<const u32x4*>((const T*)a.ap_y + off);
       hb2 |= (ok ? 1u : 0u) << k;
     }
     hbits = hb2;
+    if constexpr (APPLY) ap_coff = coff;
     if constexpr (LAZY) {
       hlazy = use0 && a.in_scale != nullptr;
       const int c0 = hlazy ? coff + (t & 7) * CH : 0;
@@ -408,9 +428,66 @@ __global__ __launch_bounds__(TW * TH * (BN >= 64 ? BN : 64) / 64, 2) void conv3x
       }
     }
   };
-  constexpr int HLOADS = HITEMS + (LAZY ? 2 * (CH / 4) : 0);   // vector-memory instructions of one halo_load
+  constexpr int HLOADS = (APPLY ? 2 : 1) * HITEMS + (LAZY ? 2 * (CH / 4) : 0);   // vector-memory instructions of one halo_load
+  // XF_APPLY: stores a writer workgroup issues per halo_store (one per item, masked lanes go out of range: every wave issues
+  // every instruction, which is what the counted s_waitcnt vmcnt(N) below relies on)
+  const int nst = ap_writer ? HITEMS : 0;
+  // XF_APPLY: the transform runs IN PLACE on the halo registers, one item per tap step of the chunk before (xf_step), so that
+  // its ~50 vector instructions per item sit under that step's LDS fragment latency instead of between the two barriers that
+  // fence the halo buffer; the coefficients come from a table in LDS (filled once per workgroup), held in registers from
+  // tap 2 to tap 8 only.
+  float k1[APPLY ? CH : 1], k2[APPLY ? CH : 1], k3[APPLY ? CH : 1];
+  const float* aptab = reinterpret_cast<const float*>(smem + Cfg::SMEM);
+  auto xf_k_load = [&]() {
+    if constexpr (APPLY) {
+      const float* kc = aptab + ap_coff + (t & 7) * CH;
+#pragma unroll
+      for (int e = 0; e < CH; e += 4) {
+        const float4 v1 = *reinterpret_cast<const float4*>(kc + e), v2 = *reinterpret_cast<const float4*>(kc + Cfg::APC + e),
+                     v3 = *reinterpret_cast<const float4*>(kc + 2 * Cfg::APC + e);
+        k1[e] = v1.x; k1[e + 1] = v1.y; k1[e + 2] = v1.z; k1[e + 3] = v1.w;
+        k2[e] = v2.x; k2[e + 1] = v2.y; k2[e + 2] = v2.z; k2[e + 3] = v2.w;
+        k3[e] = v3.x; k3[e + 1] = v3.y; k3[e + 2] = v3.z; k3[e + 3] = v3.w;
+      }
+    }
+  };
+  auto xf_item = [&](int k) {
+    if constexpr (APPLY) {
+      float d[CH], yy[CH];
+      chunk_to_f<T>(__builtin_bit_cast(uint4, hreg[k]), d);
+      chunk_to_f<T>(__builtin_bit_cast(uint4, yreg[k]), yy);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) d[e] = fmaf(k1[e], d[e], fmaf(k2[e], yy[e], k3[e]));   // bn_bwd_apply_kernel's expression
+      hreg[k] = __builtin_bit_cast(u32x4, f_to_chunk<T>(d)) & (0u - ((hbits >> k) & 1u));    // outside the image: zero padding
+    }
+  };
+  // tap step `tap` of the chunk in front of the one the registers hold: coefficients at tap 2, the items spread over taps 3 .. 8
+  auto xf_step = [&](int tap) {
+    if constexpr (APPLY) {
+      if (tap == 2) xf_k_load();
+#pragma unroll
+      for (int k = 0; k < HITEMS; ++k)
+        if (3 + (k * 6) / HITEMS == tap) xf_item(k);
+    }
+  };
   auto halo_store = [&](int buf) {
     unsigned char* hb = halo0 + buf * Cfg::HALO;
+    if constexpr (APPLY) {   // hreg holds the transformed chunk
+      const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+          a.ap_dy, 0, ap_writer ? (int)((long)a.N * H * W * a.C0 * (long)sizeof(T)) : 0, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < HITEMS; ++k) {
+        const int it = t + NT * k;
+        const int hp = it >> 3, hy = hp / HW_, hx = hp - hy * HW_;
+        if (it < HPIX * 8) *reinterpret_cast<u32x4*>(hb + hp * 128 + (((it & 7) ^ (hx & 7)) << 4)) = hreg[k];
+        if (ap_writer) {   // workgroup-uniform
+          const bool inner = it < HPIX * 8 && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW;
+          const unsigned off = (unsigned)((((n * H + y0 - 1 + hy) * W + x0 - 1 + hx) * a.C0 + ap_coff + (it & 7) * CH) * (int)sizeof(T));
+          __builtin_amdgcn_raw_buffer_store_b128(hreg[k], drs, inner ? off : 0x80000000u, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < HITEMS; ++k) {
       const int it = t + NT * k;
@@ -490,18 +567,30 @@ __global__ __launch_bounds__(TW * TH * (BN >= 64 ? BN : 64) / 64, 2) void conv3x
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < nsteps) b_dma(d / 9, d % 9, d % NS);
+  if constexpr (APPLY) {   // coefficient table -> LDS, then the first chunk's transform (nothing to hide it behind yet)
+    float* tab = reinterpret_cast<float*>(smem + Cfg::SMEM);
+    for (int i = t; i < 3 * (a.C0 >> 2); i += NT) {
+      const int j = i / (a.C0 >> 2), c4 = i - j * (a.C0 >> 2);
+      *reinterpret_cast<float4*>(tab + j * Cfg::APC + c4 * 4) = *reinterpret_cast<const float4*>(a.ap_coef + j * a.C0 + c4 * 4);
+    }
+    __syncthreads();
+    xf_k_load();
+#pragma unroll
+    for (int k = 0; k < HITEMS; ++k) xf_item(k);
+  }
   halo_store(0);
   const bool pre1 = nchunks > 1;
   if (pre1) halo_load(1);
   // younger than the tile of step 0: the D-1 other tiles and (when issued) the loads of halo 1
-  wait_vm_lgkm0((D - 1) * DPW + (pre1 ? HLOADS : 0));
+  wait_vm_lgkm0((D - 1) * DPW + nst + (pre1 ? HLOADS : 0));
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   stamp(1);
   // fp32 runs the fragment reads and the (16x slower, MFMA-bound) multiplies back to back in ONE register set: the
   // second set only costs registers there
   // (so does the lazy-input flavour of the 64-wide tiles: 11 halo registers per lane plus the BN coefficients)
-  constexpr bool PIPE = sizeof(T) == 2 && !(LAZY && BN == 64);
+  // (and the apply flavour: two tensors' halo registers; with the second fragment set the allocator spills 200 registers)
+  constexpr bool PIPE = sizeof(T) == 2 && !(LAZY && BN == 64) && !APPLY;
   if constexpr (PIPE) rd(afA, bfA, halo0, 0, 0, 0);
 
   int sb = 0;   // (9 * chunk) % NS
@@ -525,12 +614,16 @@ __global__ __launch_bounds__(TW * TH * (BN >= 64 ? BN : 64) / 64, 2) void conv3x
         mm(afA, bfA);
       } else {
         rd(afA, bfA, hb, cur, tap, 0);
+        if constexpr (APPLY) {
+          if (!last) xf_step(tap);   // the registers hold chunk + 1: its transform rides under this step's LDS latency
+        }
         mm(afA, bfA);
         rd(afA, bfA, hb, cur, tap, 1);
         mm(afA, bfA);
       }
       // ---- end of step: wait for the tile of step s + 1 (the younger ones stay in flight) and meet the other waves
       bool halo_younger = false;   // loads of a halo chunk issued after the tile of step s + 1
+      int st_younger = 0;          // XF_APPLY: write-back stores of a halo_store issued after the tile of step s + 1
       if (tap == 8) {
         if constexpr (HB == 2) {
           if (!last) {   // the other halo buffer: published by this step's barrier
@@ -540,10 +633,11 @@ __global__ __launch_bounds__(TW * TH * (BN >= 64 ? BN : 64) / 64, 2) void conv3x
         }
       } else if (tap <= D - 2) {
         halo_younger = chunk + 1 < nchunks;   // issued at tap 8 of the previous chunk (or in the prologue)
+        st_younger = nst;                     // the halo_store of THIS chunk, issued there too, in front of those loads
       }
       const int left = last ? 8 - tap : 9;            // steps after this one (capped)
       const int groups = left < 1 ? 0 : ((left < D ? left : D) - 1);
-      wait_vm_lgkm0(left < 1 ? 0 : groups * DPW + (halo_younger ? HLOADS : 0));
+      wait_vm_lgkm0(left < 1 ? 0 : groups * DPW + st_younger + (halo_younger ? HLOADS : 0));
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (tap < 8) {
@@ -673,13 +767,16 @@ __global__ __launch_bounds__(TW * TH * (BN >= 64 ? BN : 64) / 64, 2) void conv3x
   stamp(6);
 }
 
-template <typename T, int TW, int TH, int BN, int HB, int NS, bool BNR, bool LAZY>
+template <typename T, int TW, int TH, int BN, int HB, int NS, bool BNR, int XF>
 int launch_hgd_cfg_b(const ConvArgs& a, hipStream_t s) {
   using Cfg = HgdCfg<T, TW, TH, BN, HB, NS>;
-  auto kern = conv3x3_hgd_kernel<T, TW, TH, BN, HB, NS, BNR, LAZY>;
+  static_assert(HgdCfg<T, TW, TH, BN, HB, NS>::DPW + 3 * HgdCfg<T, TW, TH, BN, HB, NS>::HITEMS + 4 <= 48, "wait_vm_lgkm0 covers the largest count");
+  auto kern = conv3x3_hgd_kernel<T, TW, TH, BN, HB, NS, BNR, XF>;
+  constexpr int SMEM = Cfg::SMEM + (XF == XF_APPLY ? Cfg::APTAB : 0);
+  static_assert(2 * Cfg::SMEM > 160 * 1024 || 2 * SMEM <= 160 * 1024, "the coefficient table must not cost the second workgroup of a CU");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -690,12 +787,13 @@ int launch_hgd_cfg_b(const ConvArgs& a, hipStream_t s) {
   b.dbg = (unsigned long long*)g_debug_buffer;
   {
     const double flops = 2.0 * (double)M * a.Cout * a.Kg;
-    const double bytes = ((double)M / (a.up0 ? 4 : 1) * a.C0 + (double)M * a.C1 + (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) +
-                         (double)a.Cout * a.Kg * sizeof(T);
+    // (the fused BN-backward apply reads a second input tensor and writes the transformed one once)
+    const double bytes = ((double)M / (a.up0 ? 4 : 1) * a.C0 * (XF == XF_APPLY ? (a.ap_dy ? 3 : 2) : 1) + (double)M * a.C1 +
+                          (double)M * a.Cout * (a.accumulate ? 2 : 1)) * sizeof(T) + (double)a.Cout * a.Kg * sizeof(T);
     static const char* names[2][3] = {{"conv3x3_hg_f32_n32", "conv3x3_hg_f32_n64", "conv3x3_hg_f32_n128"},
                                       {"conv3x3_hg_bf16_n32", "conv3x3_hg_bf16_n64", "conv3x3_hg_bf16_n128"}};
     ProfScope ps(names[sizeof(T) == 2][BN == 128 ? 2 : BN == 64 ? 1 : 0], flops, bytes, s);
-    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::SMEM, s, b);
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), SMEM, s, b);
   }
   FLAIR_CHECK_LAUNCH();
   return 0;
@@ -704,11 +802,18 @@ int launch_hgd_cfg_b(const ConvArgs& a, hipStream_t s) {
 template <typename T, int TW, int TH, int BN, int HB, int NS>
 int launch_hgd_cfg(const ConvArgs& a, hipStream_t s) {
   if constexpr (BN == 32) {   // forward of decoder block 3 conv1 only: no lazy input, no fused data-gradient epilogue
-    return (a.in_scale || a.bnr_partial) ? -6 : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, false>(a, s);
+    return (a.in_scale || a.bnr_partial || a.ap_y) ? -6 : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, XF_NONE>(a, s);
   } else {
-    if (a.in_scale) return a.bnr_partial ? -6 : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, true>(a, s);
-    return a.bnr_partial ? launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, true, false>(a, s)
-                         : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, false>(a, s);
+    if (a.in_scale) return (a.bnr_partial || a.ap_y) ? -6 : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, XF_LAZY>(a, s);
+    if (a.ap_y) {   // 128-wide column blocks only (conv_hg_applicable): the 64-wide layers have a single input chunk in bf16
+      if constexpr (BN == 128)
+        return a.bnr_partial ? launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, true, XF_APPLY>(a, s)
+                             : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, XF_APPLY>(a, s);
+      else
+        return -6;
+    }
+    return a.bnr_partial ? launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, true, XF_NONE>(a, s)
+                         : launch_hgd_cfg_b<T, TW, TH, BN, HB, NS, false, XF_NONE>(a, s);
   }
 }
 
@@ -775,7 +880,13 @@ bool conv_hg_applicable(int dtype, const ConvArgs& a) {
   const int Cin = a.C0 + a.C1;
   if (a.R != 3 || a.S != 3 || a.out_mul != 1 || a.in_div != 1 || a.pad != 1) return false;
   if (a.Hout != a.Hin || a.Wout != a.Win || a.out_nchw || !a.out) return false;
-  if (a.in_scale && (hg_dma_mode() == 0 || a.bnr_partial)) return false;
+  if (a.in_scale && (hg_dma_mode() == 0 || a.bnr_partial || a.ap_y)) return false;
+  // fused BN-backward apply: one source, no upsample, the LDS-DMA kernel; the write-back has 32-bit byte offsets
+  // (at least two input chunks: the transform of chunk c + 1 hides under the tap steps of chunk c; with one chunk it is all
+  // prologue — the 64-channel layers, which are HBM-bound anyway, lost 80 us per launch that way — and 128-wide column blocks)
+  if (a.ap_y && (hg_dma_mode() == 0 || a.C1 || a.up0 || !a.ap_coef || (a.Cout % 128) != 0 || a.C0 > 512 || a.C0 < 2 * ck ||
+                 (long)a.N * a.Hout * a.Wout * a.C0 * (long)dtype_size(dtype) >= (1L << 31)))
+    return false;
   if ((Cin % ck) || (a.C0 % ck)) return false;
   // 32 output channels (decoder block 3 conv1, 128 -> 32 at 256^2: 155 GFLOP on the ridge): the LDS-DMA kernel with one
   // 32-wide column block on 256-pixel tiles; no fused data-gradient epilogues there
@@ -797,7 +908,7 @@ static int launch_hg_t(int tp, const ConvArgs& a, hipStream_t s) {
   }
   // fp32 (parity mode) is MFMA-bound at 1/16 of the bf16 rate: the register-staged kernel is as fast there; the LDS-DMA
   // kernel serves it only for a lazy BatchNorm + ReLU input
-  if (dma != 0 && (sizeof(T) == 2 || a.in_scale)) {
+  if (dma != 0 && (sizeof(T) == 2 || a.in_scale || a.ap_y)) {
     if (tp == 128) return n128 ? launch_hgd_cfg<T, 16, 8, 128, 1, 3>(a, s) : launch_hgd_cfg<T, 16, 8, 64, 1, 3>(a, s);
     if (a.Wout % 32 == 0) return n128 ? launch_hgd_cfg<T, 32, 8, 128, 1, 3>(a, s) : launch_hgd_cfg<T, 32, 8, 64, 1, 3>(a, s);
     return n128 ? launch_hgd_cfg<T, 16, 16, 128, 1, 3>(a, s) : launch_hgd_cfg<T, 16, 16, 64, 1, 3>(a, s);
@@ -816,6 +927,9 @@ int set_debug_buffer(void* p) {
   return -7;   // not a diagnostic build
 #endif
 }
+
+bool conv_bnapply_fusable(int dtype, const ConvArgs& a) { return a.ap_y && conv_hg_applicable(dtype, a); }
+bool conv_acc_src_ok(int dtype, const ConvArgs& a) { return a.acc_src && a.accumulate && a.pool_c0 == 0 && conv_hg_applicable(dtype, a); }
 
 int launch_conv_hg(int dtype, const ConvArgs& a, hipStream_t s) {
   const int tp = hg_tile_pixels(dtype, a);

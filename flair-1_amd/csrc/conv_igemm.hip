@@ -401,6 +401,10 @@ int launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
   if (a.preds_u8 && !conv_halo_preds_ok(dtype, a)) return -6;   // fused argmax: persistent small-channel kernel only
   if (a.out_sub && (a.out_nchw || a.stats || a.pool_c0 > 0 || a.bnr_partial || conv_hg_applicable(dtype, a) || conv_halo_applicable(a)))
     return -6;  // sub-sampled stores exist in the gather-form epilogue only
+  // input / epilogue options only the halo-GEMM kernels implement (fused BN-backward apply, addend from another tensor, masked store)
+  if ((a.ap_y || a.acc_src || a.bnr_mask) && !conv_hg_applicable(dtype, a)) return -6;
+  if (a.acc_src && !conv_acc_src_ok(dtype, a)) return -6;
+  if (a.bnr_mask && !a.bnr_partial) return -6;
   if (a.in_scale) {   // lazy BN + ReLU on the input: the halo-GEMM (>= 64 channels) and the small-channel halo kernel apply it
     if (conv_hg_applicable(dtype, a)) return (a.pool_c0 > 0 || a.bnr_partial) ? -6 : launch_conv_hg(dtype, a, s);
     if (!conv_halo_applicable(a) || (a.pool_c0 > 0 && !conv_tile_epilogue_ok(dtype, a))) return -6;

@@ -16,7 +16,8 @@ int bn_bwd_blocks(long rows);
 int bn_backward(int dtype, const void* dout, const void* out, const void* y, const float* mean, const float* invstd,
                 const float* gamma, long rows, int C, float* partial, float* coef, float* dgamma, float* dbeta,
                 int accumulate_param, void* dy, void* dres, int dres_accumulate, const float* mscale, const float* mshift,
-                int pre_nblk /* > 0: partial already holds that many producer-side tile sums */, hipStream_t s);
+                int pre_nblk /* > 0: partial already holds that many producer-side tile sums */,
+                int premasked /* dout is dz already (ConvArgs::bnr_mask): no mask source needed; requires pre_nblk > 0 */, hipStream_t s);
 
 int partial_rows_sum(const float* partial, int nblk, int ncols, float* out, hipStream_t s);
 int bn_stats_partial(int dtype, const void* y, long rows, int C, float* partial, float* zeros_ones, hipStream_t s);

@@ -60,7 +60,8 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
     }
   }
   // v: the stored (rounded) gradient chunk; y (and, for units with a residual branch, the ReLU output) at the same place
-  auto bnr_item = [&](const uint4& v, const uint4& ychunk, const uint4& ochunk) {
+  // returns the chunk to store: v itself, or (bnr_mask) v with the elements the ReLU switched off set to zero
+  auto bnr_item = [&](const uint4& v, const uint4& ychunk, const uint4& ochunk) -> uint4 {
     float d[CH], yy[CH], oo[CH];
     chunk_to_f<T>(v, d);
     chunk_to_f<T>(ychunk, yy);
@@ -69,9 +70,11 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
     for (int e = 0; e < CH; ++e) {
       const bool on = a.bnr_out ? (oo[e] > 0.f) : (fmaf(yy[e], msc[e], msh[e]) > 0.f);
       const float dm = on ? d[e] : 0.f;
+      d[e] = dm;
       r1[e] += dm;
       r2[e] = fmaf(dm, yy[e], r2[e]);
     }
+    return a.bnr_mask ? f_to_chunk<T>(d) : v;   // (values of T or zeros: the repack is exact)
   };
   auto bnr_finish = [&]() {   // block-uniform: every thread of the workgroup calls it
     __syncthreads();          // the C tile has been consumed; reuse its LDS
@@ -126,10 +129,10 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
 #pragma unroll
           for (int e = 0; e < CH; ++e) fa[e] += fb[e];
         }
-        const uint4 v = f_to_chunk<T>(fa);
+        uint4 v = f_to_chunk<T>(fa);
+        if (bnr) v = bnr_item(v, *reinterpret_cast<const uint4*>((const T*)a.bnr_y + (dst - out)),
+                              a.bnr_out ? *reinterpret_cast<const uint4*>((const T*)a.bnr_out + (dst - out)) : v);
         *reinterpret_cast<uint4*>(dst) = v;
-        if (bnr) bnr_item(v, *reinterpret_cast<const uint4*>((const T*)a.bnr_y + (dst - out)),
-                          a.bnr_out ? *reinterpret_cast<const uint4*>((const T*)a.bnr_out + (dst - out)) : v);
       }
     }
     if (bnr) bnr_finish();
@@ -143,6 +146,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
   constexpr int ITEMS = TileItems<T, TPIX, BN, NT>::ITEMS;
   uint4 yv[ITEMS], ov[ITEMS], av[ITEMS];
   if (bnr) tile_bnr_prefetch<T, TW, TPIX, BN, NT>(a, n, y0, x0, n0, t, yv, ov);
+  const T* asrc = (a.acc_src && a.pool_c0 == 0) ? (const T*)a.acc_src : out;
   if (acc) {
     // all read-modify-write operands in flight together (inside the store loop the compiler cannot move a load above the
     // previous item's store: eight dependent HBM round trips per thread in the epilogue of every accumulating data gradient)
@@ -154,7 +158,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
       const int nn = n0 + ch * CH;
       const bool ok = idx < TPIX * CPR && nn < a.Cout;
       const long goff = ok ? ((long)(n * H + y0 + py) * W + x0 + px) * ld + (nn - cbase) : 0;
-      av[k] = *reinterpret_cast<const uint4*>(out + goff);
+      av[k] = *reinterpret_cast<const uint4*>(asrc + goff);
     }
   }
 #pragma unroll
@@ -191,8 +195,8 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const unsigned cha
         for (int e = 0; e < CH; ++e) fa[e] += fb[e];
         v = f_to_chunk<T>(fa);
       }
+      if (bnr) v = bnr_item(v, yv[k], ov[k]);
       *reinterpret_cast<uint4*>(dst) = v;
-      if (bnr) bnr_item(v, yv[k], ov[k]);
     }
   }
   if (bnr) bnr_finish();

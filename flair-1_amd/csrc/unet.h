@@ -67,6 +67,10 @@ struct Unit {  // conv -> BN -> (+ residual) -> ReLU
   // its data-gradient kernel (ConvArgs::bnr_*); consumed (and cleared) by unit_backward
   float* bnr_partial = nullptr;
   int bnr_nblk = 0;
+  // backward: that consumer also stored the gradient MASKED by this unit's ReLU (ConvArgs::bnr_mask): the gradient buffer of
+  // `out` holds dz, which is what the identity branch of a BasicBlock receives and what the fused BatchNorm-backward apply of
+  // the unit's own data gradient (ConvArgs::ap_*) expects.  Consumed (and cleared) by unit_backward
+  bool bnr_masked = false;
 };
 
 class UNet {
@@ -168,6 +172,10 @@ class UNet {
   int residual_producer(const Act& a) const;
   void attach_bn_reduce(ConvArgs& a, const Act& target);
   std::vector<GradBuf> gbufs_;
+  // set by the BasicBlock walk just before the backward of a block's conv1: its data gradient adds this tensor (the masked
+  // gradient of the block's output = the identity branch's share) instead of reading a copy of it from its own output buffer
+  const void* acc_src_next_ = nullptr;
+  bool bwd_fuse() const;   // FLAIR_BWD_FUSE (default on): masked gradients + BatchNorm-backward apply inside the halo-GEMM data gradients
   void* grad_of(const Act& a, bool* accumulate);
   void* grad_peek(const Act& a);
 

@@ -598,11 +598,21 @@ void UNet::attach_bn_reduce(ConvArgs& a, const Act& target) {
   a.bnr_partial = alloc_f((long)nblk * 2 * u.y.C);
   u.bnr_partial = a.bnr_partial;
   u.bnr_nblk = nblk;
+  // the halo-GEMM epilogue has the ReLU mask in hand: it stores dz = gradient * mask, and the unit's own backward needs no mask
+  // source, no copy for the identity branch and no separate BatchNorm-backward apply pass (unit_backward)
+  if (bwd_fuse() && conv_hg_applicable(dtype, a)) { a.bnr_mask = 1; u.bnr_masked = true; }
 }
+
+bool UNet::bwd_fuse() const { return tune("FLAIR_BWD_FUSE", 1) != 0; }
 
 // Backward of one conv->BN->(+res)->ReLU unit.  dout = gradient w.r.t. u.out (or w.r.t. the BN
 // output when the unit was not materialised).  Produces parameter gradients, optionally the
 // residual-branch gradient dz (dres) and the input gradient (into grad_of(in0) or dx_override).
+//
+// Round 3: when the kernel that completed dout stored it masked by this unit's ReLU (Unit::bnr_masked) and the unit's data
+// gradient runs on the halo-GEMM, that kernel applies  dy = k1*dz + k2*y + k3  itself while it stages its halo and writes dy
+// once for the weight-gradient kernel, which is then forked BEHIND it: bn_bwd_apply (read dz, read y, write dy; for residual
+// units also read out, write dres) does not run for the unit.
 void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bool need_dgrad, void* dx_override,
                          bool upcat) {
   Unit& u = units_[ui];
@@ -611,9 +621,12 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
   const long rows = u.y.rows();
   void* dy = alloc((size_t)u.y.elems() * dtype_size(dtype));
   const int pre_nblk = u.bnr_nblk;
+  const bool masked = u.bnr_masked && pre_nblk > 0;
   float* partial = pre_nblk > 0 ? u.bnr_partial : alloc_f((long)bn_bwd_blocks(rows) * 2 * b.C);
-  u.bnr_partial = nullptr; u.bnr_nblk = 0;
+  u.bnr_partial = nullptr; u.bnr_nblk = 0; u.bnr_masked = false;
   float* coef = alloc_f(3 * b.C);
+  const void* acc_src = acc_src_next_;
+  acc_src_next_ = nullptr;
   // ReLU mask: units without a residual recompute it from y (out > 0 <=> y*scale + shift > 0) and skip
   // reading the activation tensor in both backward passes
   const bool mask_from_y = u.relu && u.res_unit < 0 && !u.res.p;
@@ -627,76 +640,111 @@ void UNet::unit_backward(int ui, const void* dout, void* dres, bool dres_acc, bo
   // the stem: dy feeds nothing but the weight gradient, whose kernel stages it chunk by chunk — it applies the affine itself and
   // the tensor is never written (bn_bwd_apply: 804 MB of traffic for a 268 MB operand read once)
   const bool fuse_apply = !need_dgrad && !dres && mask_from_y && wgrad_bnapply_fusable(dtype, w);
-  RUN(bn_backward(dtype, dout, (u.relu && !mask_from_y) ? u.out.p : nullptr, u.y.p, u.mean, u.invstd, params_ + b.g_off,
-                  rows, b.C, partial, coef, grads_ + b.g_off, grads_ + b.b_off, 0, fuse_apply ? nullptr : dy, dres, dres_acc ? 1 : 0,
-                  mask_from_y ? u.scale : nullptr, mask_from_y ? u.shift : nullptr, pre_nblk, s_));
+
+  // ---- data gradient, described before anything is launched: gather-form conv over dy with the flipped / transposed pack
+  enum { DG_NONE, DG_PLAIN, DG_UPCAT_TILE, DG_UPCAT_SPLIT, DG_PARITY } dg = DG_NONE;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  void *dx0 = nullptr, *dsk = nullptr, *dcat = nullptr;
+  bool acc0 = false, acc1 = false;
+  if (need_dgrad) {
+    dg = DG_PLAIN;
+    a.src0 = dy; a.C0 = u.y.C; a.C1 = 0; a.up0 = 0;
+    a.N = u.y.N; a.Hin = u.y.H; a.Win = u.y.W;
+    a.Hout = w.Hin; a.Wout = w.Win;
+    a.R = c.R; a.S = c.S; a.out_mul = 1; a.pad = c.R - 1 - c.pad; a.in_div = c.stride;
+    a.Cout = c.Cin_p;
+    a.Kg = c.Kgd; a.Kpad = c.Kpad_d;
+    a.w = base_ + c.wd;
+    a.out_ld = c.Cin_p;
+    if (upcat) {
+      // decoder conv1: the input was cat([up2(in0), in1]).  Halo-tile kernels pool / split the gradient in their
+      // epilogue; other shapes write the concatenated gradient and run the separate upcat_bwd pass.
+      const int C0 = u.in0.C, C1 = u.in1.p ? u.in1.C : 0;
+      dx0 = grad_of(u.in0, &acc0);
+      dsk = C1 ? grad_of(u.in1, &acc1) : nullptr;
+      a.pool_c0 = C0; a.out = dx0; a.out_ld = C0; a.accumulate = acc0 ? 1 : 0;
+      a.out_skip = dsk; a.out_skip_ld = C1; a.skip_accumulate = acc1 ? 1 : 0;
+      if (conv_tile_epilogue_ok(dtype, a)) {
+        dg = DG_UPCAT_TILE;
+        attach_bn_reduce(a, u.in0);   // the pooled half is the whole gradient of the previous block's output
+      } else {
+        dg = DG_UPCAT_SPLIT;
+        dcat = alloc((size_t)u.y.rows() * (C0 + C1) * dtype_size(dtype));
+        a.pool_c0 = 0; a.out_skip = nullptr; a.out = dcat; a.out_ld = C0 + C1; a.accumulate = 0;
+      }
+    } else {
+      if (dx_override) {
+        a.out = dx_override; a.accumulate = 0;
+      } else {
+        bool acc = false;
+        a.out = grad_of(u.in0, &acc);
+        a.accumulate = acc ? 1 : 0;
+        if (acc_src) {
+          // the identity branch's share arrives as a tensor of its own (the masked gradient of the block's output)
+          ConvArgs t = a;
+          t.accumulate = 1; t.acc_src = acc_src;
+          if (!acc && conv_acc_src_ok(dtype, t)) {
+            a = t;
+          } else {   // some other kernel takes this layer: put the share into the buffer first
+            if (acc) RUN(ew_add(dtype, a.out, acc_src, u.in0.elems(), s_));
+            else if (!dry_ && !err_ && hipMemcpyAsync(a.out, acc_src, (size_t)u.in0.elems() * dtype_size(dtype), hipMemcpyDeviceToDevice, s_) != hipSuccess) err_ = -14;
+            a.accumulate = 1;
+          }
+        }
+        attach_bn_reduce(a, u.in0);
+      }
+      const bool doubled = c.stride == 2 && a.Hout == 2 * u.y.H && a.Wout == 2 * u.y.W;
+      if (doubled && (c.parity_dgrad() || (c.R == 1 && c.S == 1 && c.pad == 0 && a.accumulate))) {
+        // stride-2 data gradient by output parity class: stride-1 convolutions over dY, stores interleaved into dX.
+        // A 1x1 stride-2 layer only reaches the (even, even) pixels; when accumulating, the other classes add nothing.
+        dg = DG_PARITY;
+        a.Hout = u.y.H; a.Wout = u.y.W; a.out_mul = 1; a.pad = 0; a.in_div = 1; a.out_sub = 1;
+        if (c.R == 3) {   // the four classes (1, 2, 2 and 4 taps) ride in one launch, class = blockIdx.z
+          a.ncls = 4;
+          a.R = 2; a.S = 2;
+          a.Kg = (c.Kg_cls[0] + c.Kg_cls[1] + c.Kg_cls[2] + c.Kg_cls[3]) / 4;  // mean over the classes (work accounting only)
+          a.Kpad = c.Kpad_cls[3]; a.w = base_ + c.wd_cls[3];
+          for (int cls = 0; cls < 4; ++cls) { a.cls_w[cls] = base_ + c.wd_cls[cls]; a.cls_kpad[cls] = c.Kpad_cls[cls]; }
+        }
+      }
+    }
+  }
+  // fused BatchNorm-backward apply inside the data gradient: dout is dz already (masked), nobody else wants dz (dres)
+  bool fuse_dy = false;
+  if (masked && !dres && tune("FLAIR_BWD_FUSE", 1) >= 2 && (dg == DG_PLAIN || dg == DG_UPCAT_TILE)) {
+    ConvArgs t = a;
+    t.src0 = dout; t.ap_y = u.y.p; t.ap_coef = coef; t.ap_dy = dy;
+    if (conv_bnapply_fusable(dtype, t)) { a = t; fuse_dy = true; }
+  }
+
+  // a masked gradient needs no mask source in the apply pass: the residual units' read of `out` and the others' recomputation
+  // of relu'(y) go (bn_backward still needs one on paper when it runs the reduction itself, which it does not here: pre_nblk > 0)
+  const bool nomask = masked && !dres && bwd_fuse();
+  RUN(bn_backward(dtype, dout, (u.relu && !mask_from_y && !nomask) ? u.out.p : nullptr, u.y.p, u.mean, u.invstd, params_ + b.g_off,
+                  rows, b.C, partial, coef, grads_ + b.g_off, grads_ + b.b_off, 0, (fuse_apply || fuse_dy) ? nullptr : dy, dres,
+                  dres_acc ? 1 : 0, (mask_from_y && !nomask) ? u.scale : nullptr, (mask_from_y && !nomask) ? u.shift : nullptr,
+                  pre_nblk, nomask ? 1 : 0, s_));
   if (fuse_apply) { w.dy = dout; w.fuse_y = u.y.p; w.fuse_coef = coef; w.fuse_msc = u.scale; w.fuse_msh = u.shift; }
   w.dw = grads_ + c.w_off; w.Cin_real = c.Cin; w.accumulate = 0;
   w.in_scale = u.in0.lz_scale; w.in_shift = u.in0.lz_shift;
   w.cus = side_cus(ui);
   w.partial = (float*)alloc(wgrad_workspace_bytes(dtype, w));
-  {
+  auto launch_wg = [&]() {
     hipStream_t ws = wgrad_stream();   // dy is complete on s_; nothing later on s_ writes what this kernel reads
     RUN(launch_wgrad(dtype, w, ws));
-  }
-  if (!need_dgrad) return;
-  // data gradient: gather-form conv over dy with the flipped / transposed pack
-  Act dyact = u.y;
-  dyact.p = dy;
-  ConvArgs a;
-  memset(&a, 0, sizeof(a));
-  a.src0 = dy; a.C0 = u.y.C; a.C1 = 0; a.up0 = 0;
-  a.N = u.y.N; a.Hin = u.y.H; a.Win = u.y.W;
-  a.Hout = w.Hin; a.Wout = w.Win;
-  a.R = c.R; a.S = c.S; a.out_mul = 1; a.pad = c.R - 1 - c.pad; a.in_div = c.stride;
-  a.Cout = c.Cin_p;
-  a.Kg = c.Kgd; a.Kpad = c.Kpad_d;
-  a.w = base_ + c.wd;
-  a.out_ld = c.Cin_p;
-  if (upcat) {
-    // decoder conv1: the input was cat([up2(in0), in1]).  Halo-tile kernels pool / split the gradient in their
-    // epilogue; other shapes write the concatenated gradient and run the separate upcat_bwd pass.
-    const int C0 = u.in0.C, C1 = u.in1.p ? u.in1.C : 0;
-    bool acc0 = false, acc1 = false;
-    void* dx0 = grad_of(u.in0, &acc0);
-    void* dsk = C1 ? grad_of(u.in1, &acc1) : nullptr;
-    a.pool_c0 = C0; a.out = dx0; a.out_ld = C0; a.accumulate = acc0 ? 1 : 0;
-    a.out_skip = dsk; a.out_skip_ld = C1; a.skip_accumulate = acc1 ? 1 : 0;
-    if (conv_tile_epilogue_ok(dtype, a)) {
-      attach_bn_reduce(a, u.in0);   // the pooled half is the whole gradient of the previous block's output
+  };
+  if (!fuse_dy) launch_wg();
+  switch (dg) {
+    case DG_NONE: break;
+    case DG_UPCAT_SPLIT:
       RUN(launch_conv(dtype, a, s_));
-    } else {
-      void* dcat = alloc((size_t)u.y.rows() * (C0 + C1) * dtype_size(dtype));
-      a.pool_c0 = 0; a.out_skip = nullptr; a.out = dcat; a.out_ld = C0 + C1; a.accumulate = 0;
+      RUN(upcat_bwd(dtype, dcat, dx0, acc0 ? 1 : 0, dsk, acc1 ? 1 : 0, u.y.N, u.y.H, u.y.W, u.in0.C, u.in1.p ? u.in1.C : 0, s_));
+      break;
+    default:
       RUN(launch_conv(dtype, a, s_));
-      RUN(upcat_bwd(dtype, dcat, dx0, acc0 ? 1 : 0, dsk, acc1 ? 1 : 0, u.y.N, u.y.H, u.y.W, C0, C1, s_));
-    }
-    return;
   }
-  if (dx_override) {
-    a.out = dx_override; a.accumulate = 0;
-  } else {
-    bool acc = false;
-    a.out = grad_of(u.in0, &acc);
-    a.accumulate = acc ? 1 : 0;
-    attach_bn_reduce(a, u.in0);
-  }
-  const bool doubled = c.stride == 2 && a.Hout == 2 * u.y.H && a.Wout == 2 * u.y.W;
-  if (doubled && (c.parity_dgrad() || (c.R == 1 && c.S == 1 && c.pad == 0 && a.accumulate))) {
-    // stride-2 data gradient by output parity class: stride-1 convolutions over dY, stores interleaved into dX.
-    // A 1x1 stride-2 layer only reaches the (even, even) pixels; when accumulating, the other classes add nothing.
-    a.Hout = u.y.H; a.Wout = u.y.W; a.out_mul = 1; a.pad = 0; a.in_div = 1; a.out_sub = 1;
-    if (c.R == 3) {   // the four classes (1, 2, 2 and 4 taps) ride in one launch, class = blockIdx.z
-      a.ncls = 4;
-      a.R = 2; a.S = 2;
-      a.Kg = (c.Kg_cls[0] + c.Kg_cls[1] + c.Kg_cls[2] + c.Kg_cls[3]) / 4;  // mean over the classes (work accounting only)
-      a.Kpad = c.Kpad_cls[3]; a.w = base_ + c.wd_cls[3];
-      for (int cls = 0; cls < 4; ++cls) { a.cls_w[cls] = base_ + c.wd_cls[cls]; a.cls_kpad[cls] = c.Kpad_cls[cls]; }
-    }
-    RUN(launch_conv(dtype, a, s_));
-    return;
-  }
-  RUN(launch_conv(dtype, a, s_));
+  if (fuse_dy) launch_wg();   // dy was written by the data gradient's staging pass
 }
 
 void UNet::head_bwd_impl(const void* dl) {
@@ -752,13 +800,21 @@ void UNet::encoder_bwd_impl() {
       ui = u1 - 1;
       const Act& X = units_[u1].in0;
       const void* dO = grad_peek(units_[u2].out);
+      // dO stored masked by the block's last ReLU (the data gradient that completed it, Unit::bnr_masked): it IS dz2, the
+      // identity / downsample branch takes it as it stands and bn_bwd_apply need not write a copy
+      const bool dz_ready = units_[u2].bnr_masked && units_[u2].bnr_nblk > 0 && bwd_fuse();
       if (!ds) {
-        bool acc = false;
-        void* dX = grad_of(X, &acc);
-        unit_backward(u2, dO, dX, acc, true, nullptr);   // identity branch: dX (+)= dz2
+        if (dz_ready) {
+          unit_backward(u2, dO, nullptr, false, true, nullptr);
+          acc_src_next_ = dO;   // conv1's data gradient (below): dX = dz2 + its own result
+        } else {
+          bool acc = false;
+          void* dX = grad_of(X, &acc);
+          unit_backward(u2, dO, dX, acc, true, nullptr);   // identity branch: dX (+)= dz2
+        }
       } else {
-        void* dz = alloc((size_t)units_[u2].y.elems() * dtype_size(dtype));
-        unit_backward(u2, dO, dz, false, true, nullptr);
+        void* dz = dz_ready ? const_cast<void*>(dO) : alloc((size_t)units_[u2].y.elems() * dtype_size(dtype));
+        unit_backward(u2, dO, dz_ready ? nullptr : dz, false, true, nullptr);
         // conv1 first: its stride-2 data gradient writes every pixel of dX, so the 1x1 stride-2 downsample branch
         // (no ReLU) then only accumulates into the (even, even) ones
         unit_backward(u1, grad_peek(units_[u1].out), nullptr, false, true, nullptr);

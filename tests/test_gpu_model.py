@@ -742,6 +742,42 @@ def test_fused_and_persistent_paths_agree_with_the_plain_ones(dev, dtype):
         assert worst[0] <= 0.10, worst
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 256, 512), (1, 96, 160)])
+def test_fused_bn_backward_apply_is_bit_identical_to_the_separate_pass(dev, dtype, shape):
+    """Round 3: for the units whose data gradient runs on the halo-GEMM, the kernel that completes the gradient of the unit's
+    ReLU output stores it masked (ConvArgs::bnr_mask), the unit's own data gradient applies  dy = k1*dz + k2*y + k3  while it
+    stages its halo and writes dy once for the weight-gradient kernel (ConvArgs::ap_*), and the identity branch of a BasicBlock
+    reads the masked gradient as the addend of conv1's data gradient (ConvArgs::acc_src): bn_bwd_apply does not run for them.
+    The arithmetic and every rounding are those of bn_bwd_apply_kernel, so FLAIR_BWD_FUSE=0 (the separate pass, torch's
+    BatchNorm2d backward restated at oracle/unet_resnet34.py) must give the SAME BITS: loss, every gradient, running statistics.
+    The second shape is ragged for the tile kernels (fall-backs inside the same step)."""
+    import flair_amd
+    from flair_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    B, H, W = shape
+    x = torch.randn(B, 5, H, W, generator=g).to(dev)
+    lab = torch.randint(0, 13, (B, H, W), generator=g).to(torch.uint8).to(dev)
+    res = []
+    try:
+        for fuse in (2, 1, 0):   # 2: apply inside the data gradient too; 1 (default): masked gradients + identity hand-over; 0: round 2
+            L.check(L.lib().flair_tune_set(b"FLAIR_BWD_FUSE", fuse))
+            _, m = _pair(5, 13, 11, dev, dtype)
+            tr = flair_amd.SegTrainer(m.train(), lr=0.0)
+            loss = tr.train_step(x, lab)
+            torch.cuda.synchronize()
+            res.append((loss.item(), tr.grads.clone(), m.flat_buffers().clone()))
+    finally:
+        L.lib().flair_tune_set(b"FLAIR_BWD_FUSE", 1)
+    (l1, g1, b1) = res[-1]
+    assert torch.isfinite(g1).all()
+    for mode, (l0, g0, b0) in zip((2, 1), res[:2]):
+        assert l0 == l1
+        assert torch.equal(b0, b1)
+        nz = int((g0 != g1).sum())
+        assert nz == 0, f"mode {mode}: {nz} of {g0.numel()} gradient elements differ, max |d| {float((g0 - g1).abs().max()):.3e}"
+
+
 @pytest.mark.parametrize("dtype,classes", [("f32", 13), ("bf16", 13), ("bf16", 19), ("f32", 19)])
 def test_predict_argmax_from_the_head_epilogue_equals_argmax_of_the_logits(dev, dtype, classes):
     """SegTrainer.predict takes the argmax out of the head convolution's epilogue (flair_unet_want_preds).  It must equal the
