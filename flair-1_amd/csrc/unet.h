@@ -111,6 +111,10 @@ class UNet {
   // eval-mode forward on this handle, the next eval-mode forward with the same arena and shape skips the weight pack and
   // the 46 BatchNorm-coefficient launches (both still sit in the arena at the same offsets).  One-shot: cleared by forward.
   void reuse_constants(bool on) { reuse_req_ = on; }
+  // every entry point other than forward() lays the arena out differently (the split path re-imports five feature tensors
+  // in front of the decoder units) or overwrites it: the constants of the last eval forward are gone, and so are pending
+  // one-shot requests
+  void invalidate_reuse() { last_valid_ = false; reuse_req_ = false; preds_req_ = nullptr; maxprob_req_ = nullptr; }
   // the next forward without fp32 logits writes argmax predictions [B][H][W] uint8 here (one-shot, like reuse_constants)
   void want_preds(unsigned char* p, float* maxprob) { preds_req_ = p; maxprob_req_ = maxprob; }
   void* last_dlogits_nhwc() const { return dl_nhwc_; }

@@ -473,9 +473,15 @@ void UNet::head_fwd_impl(float* logits_nchw) {
 
 int UNet::forward(const float* params, float* buffers, const float* x_nchw, float* logits_nchw, int B, int H, int W,
                   int training, void* ws, size_t ws_bytes, hipStream_t s) {
+  // one-shot requests are consumed on EVERY path out of this call (a refused shape must not leave pointers to the caller's
+  // already freed tensors behind for the next forward without logits)
+  unsigned char* const preds_now = preds_req_;
+  float* const maxprob_now = maxprob_req_;
+  const bool reuse_now = reuse_req_;
+  preds_req_ = nullptr; maxprob_req_ = nullptr; reuse_req_ = false;
   if ((H % 32) || (W % 32)) return -10;
-  reuse_ = reuse_req_ && !training && last_valid_ && ws == last_ws_ && B == last_B_ && H == last_H_ && W == last_W_;
-  reuse_req_ = false;
+  reuse_ = reuse_now && !training && last_valid_ && ws == last_ws_ && B == last_B_ && H == last_H_ && W == last_W_;
+  preds_req_ = preds_now; maxprob_req_ = maxprob_now;   // consumed by head_fwd_impl below
   begin(ws, ws_bytes, s, false);
   fwd_common_begin(params, buffers, B, H, W, training);
   const int lazy_env = tune("FLAIR_LAZY_BN", 1);
@@ -494,6 +500,7 @@ int UNet::forward(const float* params, float* buffers, const float* x_nchw, floa
 
 int UNet::encoder_forward(const float* params, float* buffers, const float* x_nchw, float* const feats[5], int B, int H,
                           int W, int training, void* ws, size_t ws_bytes, hipStream_t s) {
+  invalidate_reuse();
   if ((H % 32) || (W % 32)) return -10;
   begin(ws, ws_bytes, s, false);
   fwd_common_begin(params, buffers, B, H, W, training);
@@ -510,6 +517,7 @@ int UNet::encoder_forward(const float* params, float* buffers, const float* x_nc
 
 int UNet::decoder_forward(const float* params, float* buffers, const float* const feats[5], float* out_nchw, int B, int H,
                           int W, int training, void* ws, size_t ws_bytes, hipStream_t s) {
+  invalidate_reuse();
   if (ws != base_ || B != B_ || H != H_ || W != W_) return -11;  // must follow encoder_forward on the same arena
   s_ = s; training_ = training; params_ = params; buffers_ = buffers;
   for (int i = 0; i < 5; ++i) {  // re-import: the caller may have modified feats[-1] (model.py:60)
@@ -528,6 +536,7 @@ int UNet::decoder_forward(const float* params, float* buffers, const float* cons
 
 int UNet::head_forward(const float* params, const float* x_nchw, float* logits_nchw, int B, int H, int W, int training,
                        void* ws, size_t ws_bytes, hipStream_t s) {
+  invalidate_reuse();
   if (ws != base_ || B != B_ || H != H_ || W != W_) return -11;
   s_ = s; params_ = params; training_ = training;
   Act x = alloc_act(B, H, W, 16);
@@ -883,6 +892,7 @@ void UNet::stage_done(int stage) {
 
 int UNet::backward(const float* params, const float* dlogits_nchw, const void* dlogits_nhwc, float* grads, void* ws,
                    size_t ws_bytes, hipStream_t s, void* const* stage_events) {
+  invalidate_reuse();
   if (ws != base_ || !training_) return -11;
   s_ = s; params_ = params; grads_ = grads; top_ = fwd_top_;
   stage_events_ = stage_events;
@@ -906,6 +916,7 @@ int UNet::backward(const float* params, const float* dlogits_nchw, const void* d
 
 int UNet::head_backward(const float* params, const float* dlogits_nchw, float* dx_nchw, float* grads, void* ws,
                         size_t ws_bytes, hipStream_t s) {
+  invalidate_reuse();
   if (ws != base_ || !training_) return -11;
   s_ = s; params_ = params; grads_ = grads;
   pack_dgrad_weights();
@@ -920,6 +931,7 @@ int UNet::head_backward(const float* params, const float* dlogits_nchw, float* d
 
 int UNet::decoder_backward(const float* params, const float* dout_nchw, float* const dfeats[5], float* grads, void* ws,
                            size_t ws_bytes, hipStream_t s) {
+  invalidate_reuse();
   if (ws != base_ || !training_) return -11;
   s_ = s; params_ = params; grads_ = grads;
   pack_dgrad_weights();
@@ -938,6 +950,7 @@ int UNet::decoder_backward(const float* params, const float* dout_nchw, float* c
 
 int UNet::encoder_backward(const float* params, const float* const dfeats[5], float* grads, void* ws, size_t ws_bytes,
                            hipStream_t s) {
+  invalidate_reuse();
   if (ws != base_ || !training_) return -11;
   s_ = s; params_ = params; grads_ = grads;
   pack_dgrad_weights();

@@ -91,10 +91,14 @@ class MetadataMLP(nn.Module):
     def forward(self, x, masks="auto"):
         if not x.is_cuda:
             return self.enc_mlp(x)
-        if x.dim() != 2 or x.shape[1] != 45 or x.shape[0] > 256:
-            raise ValueError("MetadataMLP expects (B <= 256, 45) metadata vectors")
+        if x.dim() != 2 or x.shape[1] != 45:
+            raise ValueError("MetadataMLP expects (B, 45) metadata vectors")
         if masks == "auto":
             masks = self.dropout_masks(x.shape[0], x.device)
+        if x.shape[0] > 256:   # the backward kernel takes up to 256 samples per launch: larger batches go in slices
+            parts = [self.forward(x[i:i + 256], None if masks is None else [m[i:i + 256] for m in masks])
+                     for i in range(0, x.shape[0], 256)]
+            return torch.cat(parts, 0)
         l1, l2, l3 = self.enc_mlp[0], self.enc_mlp[3], self.enc_mlp[6]
         return _MlpFn.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, masks)
 

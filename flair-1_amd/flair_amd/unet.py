@@ -492,6 +492,8 @@ class Unet(nn.Module):
         chans = (64, 64, 128, 256, 512)
         feats = [torch.empty(B, c, H >> (i + 1), W >> (i + 1), dtype=torch.float32, device=x.device) for i, c in enumerate(chans)]
         arr = (C.c_void_p * 5)(*[f.data_ptr() for f in feats])
+        if not training:
+            self._eval_key = None   # the split path re-lays the eval arena: the fused forward's constants are gone
         L.check(L.lib().flair_unet_encoder_forward(self._hh(training), L.ptr(self._flat_p), L.ptr(self._flat_b), L.ptr(x), arr, B, H, W,
                                                    int(training), L.ptr(ws), ws.numel(), L.stream()), "encoder_forward")
         if training:
@@ -514,6 +516,8 @@ class Unet(nn.Module):
         feats = [f.detach().to(torch.float32).contiguous() for f in feats]
         out = torch.empty(B, 16, H, W, dtype=torch.float32, device=feats[0].device)
         arr = (C.c_void_p * 5)(*[f.data_ptr() for f in feats])
+        if not training:
+            self._eval_key = None
         L.check(L.lib().flair_unet_decoder_forward(self._hh(training), L.ptr(self._flat_p), L.ptr(self._flat_b), arr, L.ptr(out), B, H, W,
                                                    int(training), L.ptr(ws), ws.numel(), L.stream()), "decoder_forward")
         if training:
@@ -526,6 +530,8 @@ class Unet(nn.Module):
         (B, H, W), ws = self._split[bool(training)]
         x = x.detach().to(torch.float32).contiguous()
         logits = torch.empty(B, self.classes, H, W, dtype=torch.float32, device=x.device)
+        if not training:
+            self._eval_key = None
         L.check(L.lib().flair_unet_head_forward(self._hh(training), L.ptr(self._flat_p), L.ptr(x), L.ptr(logits), B, H, W, int(training),
                                                 L.ptr(ws), ws.numel(), L.stream()), "head_forward")
         return logits

@@ -68,8 +68,10 @@ class predictionwriter(_Base):
         if not preds.is_cuda:
             raise RuntimeError("predictionwriter expects device predictions (no CPU path)")
         if self._worker is None:
-            # not a daemon: tiles still queued when the interpreter exits must reach the disk (atexit drains the queue)
-            self._worker = threading.Thread(target=self._run, daemon=False)
+            # A daemon thread + an atexit hook that drains the queue: tiles still queued when the interpreter exits reach the
+            # disk, and an exit without close() cannot hang.  (A non-daemon worker is joined by threading._shutdown() BEFORE
+            # the atexit callbacks run, i.e. while it still blocks in q.get(): the stopper never fired.)
+            self._worker = threading.Thread(target=self._run, daemon=True)
             self._worker.start()
             self._copy_stream = torch.cuda.Stream(device=preds.device)
             ref = weakref.ref(self)

@@ -14,13 +14,14 @@ import torch
 
 from . import _lib as L
 
-OUTPUT_TYPES = {"argmax": 0, "class_prob": 1, "probs": 2}   # "probs": fp32 softmax, no convert (compare.py:35)
+OUTPUT_TYPES = {"argmax": 0, "class_prob": 1}   # the values config["output_type"] may take (compare.py:69-82)
+_MODE_PROBS = 2                                   # private: every fp32 softmax probability, no convert (compare.py:35)
 
 
-def detect_convert(logits: torch.Tensor, margin: int, output_type: str) -> torch.Tensor:
+def detect_convert(logits: torch.Tensor, margin: int, output_type: str, _probs: bool = False) -> torch.Tensor:
     """softmax(dim=1) -> [:, m:S-m, m:S-m] -> convert(., output_type) for a batch of square tiles.
     'argmax' -> float32 (B, 2, K, K); 'class_prob' -> uint8 (B, C, K, K)."""
-    if output_type not in OUTPUT_TYPES:
+    if not _probs and output_type not in OUTPUT_TYPES:
         raise ValueError("The output type has not been interpreted.")
     if logits.dim() != 4 or logits.shape[2] != logits.shape[3]:
         raise ValueError("logits must be (B, C, S, S)")
@@ -29,13 +30,13 @@ def detect_convert(logits: torch.Tensor, margin: int, output_type: str) -> torch
     K = S - 2 * int(margin)
     if K < 1:
         raise ValueError("margin leaves no pixel")
-    if output_type == "argmax":
-        out = torch.empty(B, 2, K, K, dtype=torch.float32, device=logits.device)
-    elif output_type == "probs":
+    if _probs:
         out = torch.empty(B, C, K, K, dtype=torch.float32, device=logits.device)
+    elif output_type == "argmax":
+        out = torch.empty(B, 2, K, K, dtype=torch.float32, device=logits.device)
     else:
         out = torch.empty(B, C, K, K, dtype=torch.uint8, device=logits.device)
-    L.check(L.lib().flair_detect_convert(L.ptr(logits), B, C, S, int(margin), OUTPUT_TYPES[output_type], L.ptr(out),
+    L.check(L.lib().flair_detect_convert(L.ptr(logits), B, C, S, int(margin), _MODE_PROBS if _probs else OUTPUT_TYPES[output_type], L.ptr(out),
                                          L.stream()), "flair_detect_convert")
     return out
 
@@ -53,7 +54,7 @@ def inference(device, model, use_gpu: bool, config: dict, samples: dict, fused: 
         if fused:
             predictions = detect_convert(logits, config["margin"], config["output_type"])
         else:   # the reference's own return value: every probability, uncropped (same HIP kernel, no ATen op on the path)
-            predictions = detect_convert(logits, 0, "probs")
+            predictions = detect_convert(logits, 0, "", _probs=True)
     indices = samples["index"].cpu().numpy()
     return predictions.cpu().numpy(), indices
 

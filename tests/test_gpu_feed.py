@@ -220,6 +220,29 @@ def test_metrics_and_writer_end_to_end(dev, tmp_path):
     assert saved["per_class_iou"] == [float(v) for v in want["per_class_iou"]] and len(saved["classes"]) == 15
 
 
+def test_writer_without_close_neither_hangs_nor_loses_tiles(tmp_path):
+    """the worker thread must not keep the interpreter alive (a non-daemon queue worker is joined before the
+    atexit hooks run) and a tile queued by a bare write_on_batch_end — no close(), no on_predict_end — must still be on disk
+    after the process has exited."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, torch
+sys.path[:0] = [r'{root}', r'{os.path.join(root, "flair-1_amd")}']
+from flair_amd.writer import predictionwriter
+w = predictionwriter({{"georeferencing_output": False}}, r'{tmp_path}', "batch")
+p = (torch.arange(2 * 32 * 32, device="cuda:0") % 19).reshape(2, 32, 32)
+w.write_on_batch_end(None, None, {{"preds": p, "id": ["a/IMG_000001.tif", "a/IMG_000002.tif"]}}, None, None, 0, 0)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    from PIL import Image
+    want = (np.arange(2 * 32 * 32) % 19).reshape(2, 32, 32).astype(np.uint8)
+    for i in (1, 2):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / f"PRED_IMG_00000{i}.tif")), want[i - 1])
+
+
 def test_zone_detect_inference_fused(dev):
     import flair_amd
     from flair_amd.zone_detect import inference

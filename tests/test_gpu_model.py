@@ -635,6 +635,24 @@ def test_metadata_mlp_kernel_matches_reference_module(dev):
     (h * w).sum().backward()
     for p, r in zip(hip.parameters(), ref):
         assert float((p.grad.cpu() - r.grad).abs().max()) <= 1e-5 * max(1.0, float(r.grad.abs().max()))
+    # any batch size, like the reference's nn.Sequential (the backward kernel takes 256 samples per launch: slices)
+    xb = torch.randn(300, 45)
+    hip.zero_grad()
+    hip.eval()
+    with torch.no_grad():
+        assert float((hip(xb.to(dev)).cpu() - mlp(xb)).abs().max()) < 1e-6
+    hip.train()
+    mb = [torch.bernoulli(torch.full((300, n), 0.6)) / 0.6 for n in (64, 32, 16)]
+    ob = hip(xb.to(dev), masks=[m.to(dev) for m in mb])
+    ob.sum().backward()
+    ref = [p.detach().clone().requires_grad_(True) for p in mlp.parameters()]
+    h = xb
+    for i in range(3):
+        h = torch.relu((h @ ref[2 * i].t() + ref[2 * i + 1]) * mb[i])
+    assert float((ob.detach().cpu() - h).abs().max()) < 1e-6
+    h.sum().backward()
+    for p, r in zip(hip.parameters(), ref):
+        assert float((p.grad.cpu() - r.grad).abs().max()) <= 2e-5 * max(1.0, float(r.grad.abs().max()))
 
 
 def test_constant_weight_reuse_in_eval_loops_is_invalidated_by_every_writer(dev):
@@ -682,6 +700,16 @@ def test_constant_weight_reuse_in_eval_loops_is_invalidated_by_every_writer(dev)
     with torch.no_grad():
         assert torch.equal(hip(y), cold(y))
     assert p0.shape == (2, 64, 64)
+    # 5. the split entry points on the same eval handle and arena lay the workspace out differently (five re-imported feature
+    #    tensors in front of the decoder units): a fused eval forward after them must not take the reuse path
+    with torch.no_grad():
+        a = hip(y)
+        assert torch.equal(hip(y), a)                      # reuse path armed
+        feats = hip.encoder(y)
+        split = hip.segmentation_head(hip.decoder(*feats))
+        again = hip(y)
+        assert torch.equal(again, cold(y))
+        assert torch.allclose(split, again, rtol=1e-4, atol=1e-4)
 
 
 ROUND2B_SWITCHES = {"FLAIR_WG_CUS": 256, "FLAIR_HALO_PERSIST": 0, "FLAIR_HALO_PM": 0, "FLAIR_BNR_HALO": 0, "FLAIR_DBIAS_FUSE": 0,
