@@ -13,6 +13,13 @@ N>1) -> SGD.  Workload = BASELINE.json configs[1]: 5-channel 512x512 tiles, 13 c
 batch 32 per GPU (weak scaling).  Rank 0 prints ONE JSON line.  Extra objects on that line:
   roofline      dominant kernel, timed live with HIP events on its launch stream during the last timed step
   cpu_baseline  the oracle (torch-CPU fp32 restatement of the reference's CPU path) on a bounded sample
+  surface       (N=1, outside the timed region) the same step driven through the reference's own surface:
+                segmentation_task_training.training_step -> loss.backward() -> torch.optim.SGD.step()
+                (task_module.py:82-86, tasks_utils.py:88-95), with uint8 labels and with the reference's fp32 one-hot mask
+                (data_loader.py:65-69), and predict_step at batch 1 (data_module.py:100)
+  exchange      (N>1) ranks that took part in a collective, every rank's own ms per step, and the exposed communication:
+                ms per step of the timed region minus ms per step of the same ranks with the gradient exchange switched off
+Rehearsal of the N>1 branch without N GPUs (tests): FLAIR_BENCH_BACKEND=gloo, FLAIR_BENCH_DEVICES=0,0 (rank -> device).
 """
 import argparse
 import ctypes as C
@@ -159,6 +166,73 @@ def roofline_obj(prof, args, full_workload, kernel=None):
             "share_of_kernel_time": round(d["ms"] / tot, 3)}
 
 
+def surface_throughput(args, dev, img, lab):
+    """tiles/s of the hot path driven the way src/flair drives it: the LightningModule mirror's
+    training_step (forward through the smp-surface module, fused criterion), loss.backward() through autograd, and
+    torch.optim.SGD.step() on the nn.Parameters; predict_step at the reference's predict batch size 1."""
+    import flair_amd
+    from flair_amd.task_module import segmentation_task_predict, segmentation_task_training
+    classes = {i + 1: [1.0, f"c{i + 1}"] for i in range(args.classes)}
+    cfg = {"model_framework": {"model_provider": "SegmentationModelsPytorch",
+                               "SegmentationModelsPytorch": {"encoder_decoder": "resnet34_unet"}},
+           "use_metadata": False, "channels": [1, 2, 3, 4, 5], "classes": classes}
+    os.environ["FLAIR_AMD_DTYPE"] = args.dtype
+    model = flair_amd.FLAIR_ModelFactory(cfg, compute_dtype=args.dtype).to(dev)
+    crit = flair_amd.FusedCrossEntropyLoss(weight=torch.ones(args.classes)).to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    task = segmentation_task_training(model, classes, criterion=crit, optimizer=opt).to(dev)
+    task.setup("fit")
+    task.train()
+    out = {"path": "flair_amd.segmentation_task_training.training_step -> loss.backward() -> torch.optim.SGD.step() "
+                   "(task_module.py:82-86, tasks_utils.py:88-95); zero_grad(set_to_none=True) as Lightning does"}
+
+    def run(batch, n):
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            task.training_step(batch, 0).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            opt.zero_grad(set_to_none=True)
+            task.training_step(batch, i).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return args.batch * n / (time.perf_counter() - t0)
+
+    n = max(3, min(args.steps, 10))
+    out["train_tiles_per_s"] = round(run({"img": img, "msk": lab}, n), 2)
+    out["train_labels"] = "uint8 class index (B,H,W)"
+    onehot = torch.zeros(args.batch, args.classes, args.size, args.size, dtype=torch.float32, device=dev)
+    onehot.scatter_(1, lab.long().unsqueeze(1), 1.0)
+    out["train_onehot_tiles_per_s"] = round(run({"img": img, "msk": onehot}, n), 2)
+    out["train_onehot_labels"] = "fp32 one-hot (B,C,H,W), the reference's batch['msk'] (data_loader.py:65-69)"
+    del onehot
+    pred = segmentation_task_predict(model, args.classes).to(dev).eval()
+    one = {"img": img[:1], "msk": lab[:1]}
+    with torch.no_grad():
+        for _ in range(3):
+            pred.predict_step(dict(one), 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m = 30
+        for i in range(m):
+            pred.predict_step(dict(one), i)
+        torch.cuda.synchronize()
+        out["predict_bs1_tiles_per_s"] = round(m / (time.perf_counter() - t0), 2)
+        big = {"img": img, "msk": lab}
+        pred.predict_step(dict(big), 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5):
+            pred.predict_step(dict(big), i)
+        torch.cuda.synchronize()
+        out["predict_bs%d_tiles_per_s" % args.batch] = round(args.batch * 5 / (time.perf_counter() - t0), 2)
+    del task, pred, model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def spawn_ranks(n, cmd, env=None, timeout=None):
     """Start `cmd` n times as ranks 0..n-1 of one node (what torch.distributed.run / Lightning's DDP launcher does for the
     reference, src/flair/tasks.py:83-88) and wait.  Rank 0 inherits stdout; the other ranks' stdout goes to stderr.
@@ -220,7 +294,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain start: become the launcher.  device_count() does not initialise the GPU on this image.
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not os.environ.get("FLAIR_BENCH_DEVICES"):
             print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible on this node", file=sys.stderr)
             raise SystemExit(2)
         raise SystemExit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
@@ -229,15 +303,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    devmap = os.environ.get("FLAIR_BENCH_DEVICES")   # rehearsal: several ranks on one GPU
+    dev_index = int(devmap.split(",")[local_rank]) if devmap else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("FLAIR_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" rehearses the branch on CPU sockets
     if world > 1 or args.force_exchange:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     import flair_amd
     from flair_amd import _lib as L
@@ -322,10 +402,39 @@ def main():
         del t32, m32
         torch.cuda.empty_cache()
 
+    exchange = None
     if world > 1:
+        own_ms = 1e3 * dt / args.steps
+        # the same ranks without the gradient exchange (each rank's own compute; the replicas drift apart from here on, which
+        # no longer matters): what the exchange leaves exposed is the difference to the timed region
+        trainer.exchange = False
+        k2 = max(2, min(args.steps, 10))
+        trainer.train_step(img, lab)
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(k2):
+            trainer.train_step(img, lab)
+        sync()
+        solo_ms = 1e3 * (time.perf_counter() - t3) / k2
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones)
+        per_rank = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([own_ms, solo_ms], dtype=torch.float64, device=dev))
         t = torch.tensor([dt, dti], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dti = float(t[0]), float(t[1])
+        solo_max = max(float(p[1]) for p in per_rank)
+        exchange = {"backend": "rccl" if backend == "nccl" else backend, "collective_ranks": int(round(float(ones[0]))),
+                    "per_rank_ms_per_step": [round(float(p[0]), 3) for p in per_rank],
+                    "ms_per_step_without_exchange": round(solo_max, 3),
+                    "exposed_comm_ms_per_step": round(1e3 * dt / args.steps - solo_max, 3),
+                    "overlap": not args.no_overlap, "buckets": len(trainer.buckets),
+                    "bucket_mbytes": [round(4e-6 * (e - b), 2) for b, e in trainer.buckets]}
+
+    # the same step through the reference's own surface (LightningModule hooks, autograd, torch.optim.SGD)
+    surface = None
+    if rank == 0 and world == 1 and not args.train_only:
+        surface = surface_throughput(args, dev, img, lab)
 
     if rank == 0:
         tiles = args.batch * world * args.steps
@@ -366,6 +475,11 @@ def main():
             res["inference_roofline"] = roofline_obj(prof_inf, args, full_workload)
         if fp32:
             res.update(fp32)
+        if exchange:
+            res["exchange"] = exchange
+        if surface:
+            surface["train_frac_of_value"] = round(surface["train_tiles_per_s"] / value, 4)
+            res["surface"] = surface
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(2, args.size, args.classes, iters=24)
         print(json.dumps(res), flush=True)

@@ -7,7 +7,11 @@ One step = what Lightning drives per batch in the reference:
 C ABI and the exchange is RCCL over xGMI: one process per GPU, gradients live in ONE flat buffer laid
 out stage by stage, the native backward records a HIP event when a stage's bucket is final, and the
 bucket's all-reduce starts on a side stream while the earlier stages are still being differentiated.
-BatchNorm statistics stay per rank (no SyncBN), like the reference.
+BatchNorm batch statistics stay per rank (no SyncBN), like the reference; the RUNNING statistics are rank 0's on every
+rank, like torch DDP's ``broadcast_buffers=True`` (the default Lightning's 'ddp' strategy keeps) leaves them: DDP sends rank
+0's buffers to every rank in front of each forward, which for BatchNorm is the same as sending them behind each training
+step — done here with one small broadcast per step on the exchange stream — so validation, predict, ``state_dict()`` and
+checkpoints see rank 0's statistics on every rank without a collective of their own.
 """
 from __future__ import annotations
 
@@ -67,8 +71,10 @@ class SegTrainer:
     """Owns the flat gradient buffer, the fused head outputs and the RCCL exchange for one rank."""
 
     def __init__(self, model, lr, class_weight=None, group=None, overlap=True, min_bucket_elems=1 << 18,
-                 force_exchange=False):
+                 force_exchange=False, broadcast_buffers=True):
         self.model = model
+        self.sync_buffers = bool(broadcast_buffers)   # torch DDP's broadcast_buffers (tasks.py:83-88 keeps the default, True)
+        self._src0 = 0 if group is None else dist.get_global_rank(group, 0)
         self.lr = float(lr)
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -98,8 +104,8 @@ class SegTrainer:
             # bucket -> the stage whose completion makes it ready (its lowest stage)
             sr = model.stage_ranges()
             self._bucket_stage = [min(s for s, (b, e) in enumerate(sr) if b >= bb and e <= be and e > b) for bb, be in self.buckets]
-            dist.broadcast(p, src=0, group=group)  # DDP's initial parameter broadcast
-            dist.broadcast(model.flat_buffers(), src=0, group=group)
+            dist.broadcast(p, src=self._src0, group=group)  # DDP's initial parameter broadcast
+            dist.broadcast(model.flat_buffers(), src=self._src0, group=group)
 
     def _buffers(self, B, H, W):
         m = self.model
@@ -133,10 +139,13 @@ class SegTrainer:
             m._c_backward(dlogits_nhwc=self._dl, grads=self.grads, stage_events=self.events)
             works = []
             with torch.cuda.stream(self.comm_stream):
-                for (b, e), st in zip(self.buckets, self._bucket_stage):
+                for i, ((b, e), st) in enumerate(zip(self.buckets, self._bucket_stage)):
                     self.comm_stream.wait_event(self.events[st])
                     if self._no_collective:   # diagnostic (FLAIR_REHEARSE_NO_COLLECTIVE=1): stage events and waits only
                         continue
+                    if i == 0 and self.sync_buffers:
+                        # the first stage event lies behind the whole forward: this step's running statistics are final
+                        works.append(dist.broadcast(m.flat_buffers(), src=self._src0, group=self.group, async_op=True))
                     works.append(dist.all_reduce(self.grads[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             for w in works:
                 w.wait()
@@ -144,6 +153,8 @@ class SegTrainer:
             m._c_backward(dlogits_nhwc=self._dl, grads=self.grads)
             if self.exchange:
                 allreduce_buckets(self.grads, self.buckets, self.group)
+                if self.sync_buffers:
+                    dist.broadcast(m.flat_buffers(), src=self._src0, group=self.group)
         # DDP averages: fold 1/world into the step size
         ops.sgd_step_(m._flat_p, self.grads, self.lr / self.world)
         m._native_writes = m.__dict__.get("_native_writes", 0) + 1   # parameters changed behind torch's version counter

@@ -43,7 +43,11 @@ def _worker(rank, world, port, overlap, out):
     for _ in range(2):
         loss = trainer.train_step(img.to(dev), lab.to(dev))
     torch.cuda.synchronize()
-    out[rank] = (model.flat_parameters().detach().cpu(), float(loss))
+    # eval-mode forward on each rank WITHOUT any collective of its own: the running statistics must already be rank 0's
+    model.eval()
+    with torch.no_grad():
+        ev = model(_batch(7)[0].to(dev)).cpu()
+    out[rank] = (model.flat_parameters().detach().cpu(), float(loss), model.flat_buffers().detach().cpu(), ev)
     dist.destroy_process_group()
 
 
@@ -78,3 +82,32 @@ def test_two_ranks_one_gpu_match_single_process_average(dev, overlap):
     assert err < 2e-6, err  # (g0 + g1) * (lr / 2) vs ((g0 + g1) / 2) * lr: rounding only
     start = _model(100).to(dev).flat_parameters().detach().cpu()
     assert (w0 - start).abs().max() > 1e-4  # and the step did move the weights
+    # torch DDP broadcast_buffers=True (tasks.py:83-88 keeps the default): every rank holds RANK 0's running statistics — the
+    # ones a single process fed rank 0's batches accumulates — so rank 1's eval logits equal rank 0's bit for bit
+    assert torch.equal(out[0][2], out[1][2])
+    assert torch.equal(out[0][3], out[1][3])
+    b_ref = reps[0].flat_buffers().detach().cpu()
+    assert torch.allclose(out[1][2], b_ref, rtol=1e-5, atol=1e-6), float((out[1][2] - b_ref).abs().max())
+    assert not torch.allclose(out[1][2], reps[1].flat_buffers().detach().cpu(), rtol=1e-3, atol=1e-4)   # (rank 1's own differ)
+
+
+def test_bench_n_gt_1_branch_runs_end_to_end_on_gloo():
+    """Every line of bench.py's N>1 branch (self-spawned ranks, process group, per-rank tiles, barrier + max-over-ranks timing,
+    the exchange object) executed once before the driver's 8-GPU RCCL run: two ranks on the one GPU of this box, gloo instead
+    of RCCL (FLAIR_BENCH_BACKEND / FLAIR_BENCH_DEVICES), small tiles."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FLAIR_BENCH_BACKEND="gloo", FLAIR_BENCH_DEVICES="0,0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+                        "--size", "64", "--dtype", "f32", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["scaling"] == "weak"
+    ex = line["exchange"]
+    assert ex["collective_ranks"] == 2 and ex["backend"] == "gloo" and len(ex["per_rank_ms_per_step"]) == 2
+    assert line["value"] > 0 and abs(line["value"] - 4 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-2 * line["value"]
+    assert "surface" not in line and "cpu_baseline" not in line   # rank 0 at N = 1 only
