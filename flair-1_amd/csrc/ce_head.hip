@@ -368,15 +368,15 @@ int ce_head(const CeArgs& a, hipStream_t s) {
   FLAIR_CHECK_LAUNCH();
   if (a.logits_nhwc) {
     const int ld = a.logits_ld;
-    if ((ld != 16 && ld != 32) || ld < a.C || a.dlogits_nchw || a.preds_i64 || (a.dlogits_nhwc && (a.dlogits_ld != ld || a.dlogits_dtype != a.logits_dtype)))
+    if ((ld != 16 && ld != 24 && ld != 32) || ld < a.C || a.dlogits_nchw || a.preds_i64 || (a.dlogits_nhwc && (a.dlogits_ld != ld || a.dlogits_dtype != a.logits_dtype)))
       return -3;
     ProfScope ps("ce_main", 0.0, (double)npix * (2.0 * ld * dtype_size(a.logits_dtype) + 2), s);
     if (a.logits_dtype == DT_F32) {
-      auto kern = ld == 16 ? ce_main_nhwc_kernel<float, 16> : ce_main_nhwc_kernel<float, 32>;
+      auto kern = ld == 16 ? ce_main_nhwc_kernel<float, 16> : ld == 24 ? ce_main_nhwc_kernel<float, 24> : ce_main_nhwc_kernel<float, 32>;
       hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, (const float*)a.logits_nhwc, lab8, a.weight, den, a.C, npix, loss_partial,
                          a.dlogits_nhwc, a.dlogits_ld, a.preds_u8, a.confmat);
     } else {
-      auto kern = ld == 16 ? ce_main_nhwc_kernel<bf16_t, 16> : ce_main_nhwc_kernel<bf16_t, 32>;
+      auto kern = ld == 16 ? ce_main_nhwc_kernel<bf16_t, 16> : ld == 24 ? ce_main_nhwc_kernel<bf16_t, 24> : ce_main_nhwc_kernel<bf16_t, 32>;
       hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, (const bf16_t*)a.logits_nhwc, lab8, a.weight, den, a.C, npix, loss_partial,
                          a.dlogits_nhwc, a.dlogits_ld, a.preds_u8, a.confmat);
     }

@@ -119,7 +119,7 @@ class UNet {
   void want_preds(unsigned char* p, float* maxprob) { preds_req_ = p; maxprob_req_ = maxprob; }
   void* last_dlogits_nhwc() const { return dl_nhwc_; }
   const void* logits_nhwc() const { return logits_nhwc_; }
-  int head_ld() const { return 16 > classes ? 16 : (int)round_up(classes, 8); }
+  int head_ld() const { return convs.back().Cout_p; }
 
  private:
   // ---- arena

@@ -26,7 +26,11 @@ int UNet::add_conv(const std::string& name, int cin, int cout, int k, int stride
   ConvDesc c;
   c.name = name; c.Cin = cin; c.Cout = cout; c.R = k; c.S = k; c.stride = stride; c.pad = pad; c.bias = bias;
   c.Cin_p = (int)round_up(cin, 8);
-  c.Cout_p = cout < 16 ? 16 : (int)round_up(cout, 8);
+  // stored output channels: whole 32-byte (bf16) / 64-byte (fp32) groups.  Every layer of the graph is a multiple of 16 already;
+  // the head's 13 classes take 16 columns, 19 classes 32 — with 24 (whole 16-byte chunks only, rounds 1-2) the head's backward had
+  // no tile kernel (its data gradient has Cout_p INPUT channels, its weight gradient dy rows of Cout_p) and the lazy-BN training
+  // path of the fused trainer refused 19 classes
+  c.Cout_p = (int)round_up(cout < 16 ? 16 : cout, 16);
   c.w_off = n_params;
   TensorInfo t;
   t.name = name + ".weight"; t.ndim = 4; t.shape[0] = cout; t.shape[1] = cin; t.shape[2] = k; t.shape[3] = k;

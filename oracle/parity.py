@@ -7,7 +7,7 @@ own rounding noise has no defined winner.  The rule (task_module.py:71-79 takes 
     * ZERO mismatches among pixels whose oracle top-2 softmax-probability gap exceeds GAP = 1e-5;
     * every mismatch is counted and the largest gap among the mismatching pixels is reported;
     * the confusion matrix is compared exactly over the decided pixels.
-Each call appends a record to the parity log (FLAIR_PARITY_JSON, default gpurun_out/r2_parity.json under the repo root
+Each call appends a record to the parity log (FLAIR_PARITY_JSON, default gpurun_out/r3_parity.json under the repo root
 when that directory exists), which is copied to profiles/ each round.
 """
 import json
@@ -35,7 +35,7 @@ def _log_path():
         return p
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = os.path.join(root, "gpurun_out")
-    return os.path.join(d, "r2_parity.json") if os.path.isdir(d) else None
+    return os.path.join(d, "r3_parity.json") if os.path.isdir(d) else None
 
 
 def record(entry: dict):
@@ -86,7 +86,7 @@ def assert_mask_parity(name, mask_ref, mask_hip, gap, logits_ref=None, logits_hi
     return entry
 
 
-def assert_masks_within_logit_error(name, logits_ref, logits_hip, mask_hip, max_rel_dlogit=5e-3, axis=1):
+def assert_masks_within_logit_error(name, logits_ref, logits_hip, mask_hip, max_rel_dlogit=5e-3, axis=1, max_rel_rms=None):
     """For comparisons where the two sides do NOT hold identical weights (after a training step each side has applied its
     own fp32 gradient; the two agree to ~1e-4 per weight, and an eval-mode forward of a freshly initialised network —
     running statistics one step old — amplifies that to ~1e-3 of the logit scale): with delta = max |logit difference|,
@@ -104,10 +104,14 @@ def assert_masks_within_logit_error(name, logits_ref, logits_hip, mask_hip, max_
     diff = mask_ref != mask_hip
     flips = int(diff.sum())
     worst = float(lgap[diff].max()) if flips else 0.0
+    err = np.abs(lr - lh)
     entry = {"test": name, "pixels": int(mask_ref.size), "flips": flips, "max_abs_dlogit": delta,
+             "rms_dlogit": float(np.sqrt((err ** 2).mean())), "p999_abs_dlogit": float(np.quantile(err, 0.999)),
              "max_logit_gap_among_flipped": worst, "logit_scale": float(np.abs(lr).max()),
              "rule": "flip only where top-2 logit gap <= 2 * max|dlogit|; max|dlogit| <= %g * max(1, max|logit|)" % max_rel_dlogit}
     record(entry)
     assert delta <= max_rel_dlogit * max(1.0, float(np.abs(lr).max())), entry
     assert worst <= 2.0 * delta + 1e-12, entry
+    if max_rel_rms is not None:
+        assert entry["rms_dlogit"] <= max_rel_rms * max(1.0, entry["logit_scale"]), entry
     return entry
