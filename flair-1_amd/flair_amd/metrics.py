@@ -85,78 +85,80 @@ class MaskConfusion:
         return self.confmat.cpu().numpy()
 
 
+# metrics.json layout (metrics.py:90-108): the five averages in this order, then the kept class names and four per-class lists
+_AVG_NAMES = ("mIoU", "Overall Accuracy", "Fscore", "Precision", "Recall")
+
+
 def metrics_from_confmat(sum_confmat: np.ndarray, classes: dict) -> dict:
-    """metrics.py:76-108: drop the weight-0 classes, then the dict that becomes metrics.json."""
-    weights = np.array([classes[i][0] for i in classes])
-    unused_classes = np.where(weights == 0)[0]
-    confmat_cleaned = np.delete(np.delete(sum_confmat, unused_classes, axis=0), unused_classes, axis=1)
-    per_c_ious, avg_ious = class_IoU(confmat_cleaned, len(np.nonzero(weights)[0]))
-    ovr_acc = overall_accuracy(confmat_cleaned)
-    per_c_precision, avg_precison = class_precision(confmat_cleaned)
-    per_c_recall, avg_recall = class_recall(confmat_cleaned)
-    per_c_fscore, avg_fscore = class_fscore(per_c_precision, per_c_recall)
-    return {
-        "Avg_metrics_name": ["mIoU", "Overall Accuracy", "Fscore", "Precision", "Recall"],
-        "Avg_metrics": [avg_ious, ovr_acc, avg_fscore, avg_precison, avg_recall],
-        "classes": list(np.array([classes[i][1] for i in classes])[np.nonzero(weights)[0]]),
-        "per_class_iou": list(per_c_ious),
-        "per_class_fscore": list(per_c_fscore),
-        "per_class_precision": list(per_c_precision),
-        "per_class_recall": list(per_c_recall),
-    }
+    """What the reference derives from the summed confusion matrix (metrics.py:76-108): classes of weight 0 leave the matrix
+    (rows and columns), the IoU / OA / F-score / precision / recall family is computed on the rest."""
+    keep = [n for n, k in enumerate(classes) if classes[k][0] != 0]
+    cm = np.asarray(sum_confmat)[np.ix_(keep, keep)]
+    iou, miou = class_IoU(cm, len(keep))
+    prec, mprec = class_precision(cm)
+    rec, mrec = class_recall(cm)
+    f1, mf1 = class_fscore(prec, rec)
+    names = [classes[k][1] for k in classes]
+    out = {"Avg_metrics_name": list(_AVG_NAMES), "Avg_metrics": [miou, overall_accuracy(cm), mf1, mprec, mrec],
+           "classes": list(np.array(names)[keep])}
+    for key, per_class in (("iou", iou), ("fscore", f1), ("precision", prec), ("recall", rec)):
+        out["per_class_" + key] = list(per_class)
+    return out
+
+
+def _raster_pairs(test_csv, path_preds: Path):
+    """(index, truth path, prediction path) per row of the test CSV: column 0 names the image (its basename gives
+    PRED_<name>), column 1 the truth mask (metrics.py:45-55)."""
+    import pandas as pd
+    rows = pd.read_csv(test_csv, header=None)
+    for u, (img, msk) in enumerate(zip(rows.iloc[:, 0], rows.iloc[:, 1])):
+        yield u, msk, (path_preds / ("PRED_" + str(img).split("/")[-1])).as_posix()
 
 
 def metrics(config: dict, path_preds, remove_preds: bool = False, device="cuda", chunk_tiles: int = 64):
     """Same inputs and outputs as the reference's ``metrics`` (metrics.py:44-125): test CSV -> truth rasters,
-    ``PRED_<name>`` rasters under ``path_preds`` -> ``<out>/metrics/{confmat.npy, metrics.json}``; returns the dict."""
-    import pandas as pd
+    ``PRED_<name>`` rasters under ``path_preds`` -> ``<out>/metrics/{confmat.npy, metrics.json}``; returns the dict.
+    A pair that cannot be read or whose sizes differ is reported and skipped, like the reference's try/except."""
     from PIL import Image
 
     path_preds = Path(path_preds)
-    gt_csv = pd.read_csv(config["paths"]["test_csv"], header=None)
-    truth_images = gt_csv.iloc[:, 0].to_list()
-    truth_msks = gt_csv.iloc[:, 1].to_list()
-    preds_msks = [Path(path_preds.as_posix(), "PRED_" + i.split("/")[-1]).as_posix() for i in truth_images]
-    assert len(truth_msks) == len(preds_msks), "[WARNING !] mismatch number of predictions and test files."
     print("-- Calculating metrics --")
     acc = MaskConfusion(len(config["classes"]), device=device)
-    pend_t, pend_p = [], []
+    pending = ([], [])
 
     def flush():
-        if pend_t:
-            t = torch.from_numpy(np.concatenate(pend_t)).to(device, non_blocking=True)
-            p = torch.from_numpy(np.concatenate(pend_p)).to(device, non_blocking=True)
-            acc.update(t, p)
-            pend_t.clear()
-            pend_p.clear()
+        if pending[0]:
+            acc.update(*(torch.from_numpy(np.concatenate(side)).to(device, non_blocking=True) for side in pending))
+            pending[0].clear()
+            pending[1].clear()
 
-    for u in range(len(truth_msks)):
+    for u, truth_path, pred_path in _raster_pairs(config["paths"]["test_csv"], path_preds):
         try:
-            target = _as_u8(np.asarray(Image.open(truth_msks[u])), truth=True)
-            preds = _as_u8(np.asarray(Image.open(preds_msks[u])), truth=False)
+            target = _as_u8(np.asarray(Image.open(truth_path)), truth=True)
+            preds = _as_u8(np.asarray(Image.open(pred_path)), truth=False)
             if target.size != preds.size:
                 raise ValueError("Found input variables with inconsistent numbers of samples")
-            pend_t.append(target.reshape(-1))
-            pend_p.append(preds.reshape(-1))
-        except Exception as e:  # noqa: BLE001 (the reference reports and skips the pair)
+        except Exception as e:  # noqa: BLE001
             print(f"Error at index {u}: {e}")
-        if len(pend_t) >= chunk_tiles:
+            continue
+        pending[0].append(target.reshape(-1))
+        pending[1].append(preds.reshape(-1))
+        if len(pending[0]) >= chunk_tiles:
             flush()
     flush()
     sum_confmat = acc.compute()
     out = metrics_from_confmat(sum_confmat, config["classes"])
 
-    out_folder_metrics = Path("/".join(path_preds.as_posix().split("/")[:-1]), "metrics")
-    out_folder_metrics.mkdir(exist_ok=True, parents=True)
-    np.save(out_folder_metrics.as_posix() + "/confmat.npy", sum_confmat)
-    json.dump(out, open(out_folder_metrics / Path("metrics.json"), "w"))
-
-    print("")
-    print("Global Metrics: ")
-    print("-" * 90)
-    for metric_name, metric_value in zip(out["Avg_metrics_name"], out["Avg_metrics"]):
-        print(f"{metric_name:<20s} {metric_value:<20.4f}")
-    print("-" * 90 + "\n\n")
+    folder = path_preds.parent / "metrics"
+    folder.mkdir(exist_ok=True, parents=True)
+    np.save(folder / "confmat.npy", sum_confmat)
+    with open(folder / "metrics.json", "w") as f:
+        json.dump(out, f)
+    rule = "-" * 90
+    print("\nGlobal Metrics: \n" + rule)
+    for name, value in zip(out["Avg_metrics_name"], out["Avg_metrics"]):
+        print(f"{name:<20s} {value:<20.4f}")
+    print(rule + "\n\n")
     if remove_preds:
         import shutil
         shutil.rmtree(path_preds)

@@ -47,95 +47,114 @@ def fused_step(logits, msk, criterion):
     return loss, preds.flatten(start_dim=1), targets.flatten(start_dim=1)
 
 
+class _Phase:
+    """Running loss and Jaccard state of one phase ('train' / 'val') of an epoch."""
+
+    def __init__(self, num_classes, device, per_class):
+        self.loss = MeanMetric().to(device)
+        self.miou = MulticlassJaccardIndex(num_classes=num_classes, average="weighted").to(device)
+        self.iou = MulticlassJaccardIndex(num_classes=num_classes, average=None).to(device) if per_class else None
+
+    def update(self, loss, preds, targets):
+        self.loss.update(loss)
+        self.miou(preds=preds, target=targets)
+        if self.iou is not None:
+            self.iou(preds=preds, target=targets)
+
+    def finish(self):
+        out = (self.loss.compute(), self.miou.compute(), None if self.iou is None else self.iou.compute())
+        for m in (self.loss, self.miou, self.iou):
+            if m is not None:
+                m.reset()
+        return out
+
+
+# attribute names of the reference's module (task_module.py:31-51) -> (phase, member of _Phase)
+_LEGACY = {"train_loss": ("train", "loss"), "train_metrics": ("train", "miou"), "val_loss": ("val", "loss"),
+           "val_metrics": ("val", "miou"), "val_iou": ("val", "iou")}
+_LOG_KW = dict(on_step=False, on_epoch=True, logger=True, rank_zero_only=True, sync_dist=True)
+
+
 class segmentation_task_training(_Base):
+    """The reference's LightningModule (task_module.py:8-168) by interface: constructor arguments, hook names, logged keys
+    (train_loss, val_loss, val_miou, val_iou_<class> for classes of non-zero weight) and the ``*_epoch_*`` attributes Lightning
+    callbacks read.  ``step`` is the fused kernel launch; the epoch bookkeeping is one small state object per phase."""
+
     def __init__(self, model, class_infos: dict, criterion=None, optimizer=None, use_metadata: bool = False,
                  scheduler: bool = None):
         super().__init__()
-        self.model = model
-        self.criterion = criterion
-        self.optimizer = optimizer
-        self.scheduler = scheduler
+        self.model, self.criterion, self.optimizer, self.scheduler = model, criterion, optimizer, scheduler
         self.use_metadata = use_metadata
         self.num_classes = len(class_infos)
-        self.class_names = [class_infos[i][1] for i in class_infos]
-        self.class_weigths = [class_infos[i][0] for i in class_infos]
+        self.class_names = [v[1] for v in class_infos.values()]
+        self.class_weigths = [v[0] for v in class_infos.values()]   # (the reference's spelling)
+        object.__setattr__(self, "_phases", {})
 
     def setup(self, stage=None):
         dev = next(self.model.parameters()).device
-        if stage == "fit":
-            self.train_epoch_loss, self.val_epoch_loss = None, None
-            self.train_epoch_metrics, self.val_epoch_metrics = None, None
-            self.train_metrics = MulticlassJaccardIndex(num_classes=self.num_classes, average="weighted").to(dev)
-            self.val_metrics = MulticlassJaccardIndex(num_classes=self.num_classes, average="weighted").to(dev)
-            self.val_iou = MulticlassJaccardIndex(num_classes=self.num_classes, average=None).to(dev)
-            self.train_loss = MeanMetric().to(dev)
-            self.val_loss = MeanMetric().to(dev)
-        elif stage == "validate":
-            self.val_epoch_loss, self.val_epoch_metrics = None, None
-            self.val_metrics = MulticlassJaccardIndex(num_classes=self.num_classes, average="weighted").to(dev)
-            self.val_loss = MeanMetric().to(dev)
+        wanted = {"fit": ("train", "val"), "validate": ("val",)}.get(stage, ())
+        for ph in wanted:
+            # 'fit' tracks the per-class IoU of the validation phase as well (task_module.py:43-46)
+            self._phases[ph] = _Phase(self.num_classes, dev, per_class=(ph == "val" and stage == "fit"))
+            setattr(self, ph + "_epoch_loss", None)
+            setattr(self, ph + "_epoch_metrics", None)
+
+    def __getattr__(self, name):
+        if name in _LEGACY:
+            ph, member = _LEGACY[name]
+            phases = self.__dict__.get("_phases", {})
+            if ph in phases:
+                return getattr(phases[ph], member)
+        return super().__getattr__(name)
 
     def forward(self, input_im, input_met):
         return self.model(input_im, input_met)
 
     def step(self, batch):
-        if self.use_metadata:
-            images, metadata, targets = batch["img"], batch["mtd"], batch["msk"]
-        else:
-            images, metadata, targets = batch["img"], "", batch["msk"]
-        logits = self.forward(images, metadata)
-        return fused_step(logits, targets, self.criterion)
+        meta = batch["mtd"] if self.use_metadata else ""
+        return fused_step(self.forward(batch["img"], meta), batch["msk"], self.criterion)
+
+    def _run(self, phase, batch):
+        loss, preds, targets = self.step(batch)
+        self._phases[phase].update(loss, preds, targets)
+        return loss
 
     def training_step(self, batch, batch_idx):
-        loss, preds, targets = self.step(batch)
-        self.train_loss.update(loss)
-        self.train_metrics(preds=preds, target=targets)
-        return loss
-
-    def _log(self, *a, **k):
-        if hasattr(super(), "log") and _Base is not nn.Module:
-            self.log(*a, **k)
-
-    def on_train_epoch_end(self):
-        self.train_epoch_loss = self.train_loss.compute()
-        self.train_epoch_metrics = self.train_metrics.compute()
-        self._log("train_loss", self.train_epoch_loss, on_step=False, on_epoch=True, prog_bar=True, logger=True,
-                  rank_zero_only=True, sync_dist=True)
-        self.train_loss.reset()
-        self.train_metrics.reset()
+        return self._run("train", batch)
 
     def validation_step(self, batch, batch_idx):
-        loss, preds, targets = self.step(batch)
-        self.val_loss.update(loss)
-        self.val_metrics(preds=preds, target=targets)
-        self.val_iou(preds=preds, target=targets)
-        return loss
+        return self._run("val", batch)
+
+    def _log(self, name, value, prog_bar=True):
+        if _Base is not nn.Module:   # a real LightningModule
+            self.log(name, value, prog_bar=prog_bar, **_LOG_KW)
+
+    def _finish(self, phase):
+        loss, miou, per_class = self._phases[phase].finish()
+        setattr(self, phase + "_epoch_loss", loss)
+        setattr(self, phase + "_epoch_metrics", miou)
+        self._log(phase + "_loss", loss)
+        return miou, per_class
+
+    def on_train_epoch_end(self):
+        self._finish("train")
 
     def on_validation_epoch_end(self):
-        self.val_epoch_loss = self.val_loss.compute()
-        self.val_epoch_metrics = self.val_metrics.compute()
-        iou_per_class = self.val_iou.compute()
-        self._log("val_loss", self.val_epoch_loss, on_step=False, on_epoch=True, prog_bar=True, logger=True,
-                  rank_zero_only=True, sync_dist=True)
-        self._log("val_miou", self.val_epoch_metrics, on_step=False, on_epoch=True, prog_bar=True, logger=True,
-                  rank_zero_only=True, sync_dist=True)
+        miou, per_class = self._finish("val")
+        self._log("val_miou", miou)
         self.val_iou_per_class = {}
-        for class_name, class_weight, iou in zip(self.class_names, self.class_weigths, iou_per_class):
-            if class_weight == 0:
-                continue
-            self.val_iou_per_class[class_name] = iou
-            self._log(f"val_iou_{class_name}", iou.item(), on_step=False, on_epoch=True, prog_bar=False, logger=True,
-                      rank_zero_only=True, sync_dist=True)
-        self.val_loss.reset()
-        self.val_metrics.reset()
-        self.val_iou.reset()
+        if per_class is not None:
+            for name, weight, iou in zip(self.class_names, self.class_weigths, per_class):
+                if weight != 0:
+                    self.val_iou_per_class[name] = iou
+                    self._log(f"val_iou_{name}", iou.item(), prog_bar=False)
 
     def configure_optimizers(self):
-        if self.scheduler is not None:
-            lr_scheduler_config = {"scheduler": self.scheduler, "interval": "epoch", "monitor": "val_loss",
-                                   "frequency": 1, "strict": True, "name": "Scheduler"}
-            return {"optimizer": self.optimizer, "lr_scheduler": lr_scheduler_config}
-        return self.optimizer
+        if self.scheduler is None:
+            return self.optimizer
+        return {"optimizer": self.optimizer,
+                "lr_scheduler": {"scheduler": self.scheduler, "interval": "epoch", "monitor": "val_loss", "frequency": 1,
+                                 "strict": True, "name": "Scheduler"}}
 
 
 class segmentation_task_predict(_Base):
