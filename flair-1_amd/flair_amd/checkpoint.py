@@ -25,65 +25,68 @@ def _read(path):
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
+_BAR = "#" * 63
+
+
+def _state_dict_of(path):
+    """The tensor dict inside a checkpoint file: Lightning ``.ckpt`` keeps it under ``state_dict``, ``.pth`` / ``.pt`` ARE it;
+    None for any other extension (main.py:98-106)."""
+    ext = os.path.splitext(str(path))[1]
+    if ext not in (".ckpt", ".pth", ".pt"):
+        return None
+    blob = _read(path)
+    return blob.get("state_dict", blob) if ext == ".ckpt" else blob
+
+
+def _fail(message, exit_on_fail):
+    print(message)
+    if exit_on_fail:
+        raise SystemExit()
+
+
 def load_checkpoint(conf, seg_module, exit_on_fail=False):
-    print()
-    print("###############################################################")
-    ckpt_file_path = conf["paths"]["ckpt_model_path"]
-    num_classes = len(conf["classes"])
-    if ckpt_file_path and os.path.isfile(ckpt_file_path):
-        checkpoint = _read(ckpt_file_path)
-        if ckpt_file_path.endswith(".ckpt"):
-            state_dict = checkpoint.get("state_dict", checkpoint)
-        elif ckpt_file_path.endswith(".pth") or ckpt_file_path.endswith(".pt"):
-            state_dict = checkpoint
-        else:
-            print("Invalid file extension.")
-            if exit_on_fail:
-                raise SystemExit()
-            return
-        ckpt_num_classes = None
-        for k, v in state_dict.items():
-            if "classifier.weight" in k or "criterion.weight" in k:
-                ckpt_num_classes = v.shape[0]
-                break
-        model_state_dict = seg_module.state_dict()
-        if ckpt_num_classes is not None and ckpt_num_classes == num_classes:
-            seg_module.load_state_dict(state_dict, strict=False)
+    """main.py:76-146: load the weights; when the file was trained for another class count, the head / criterion tensors whose
+    shapes differ are replaced (criterion.weight <- the config's class weights, head tensors <- zeros of the first
+    ``num_classes`` rows) and everything else loads non-strictly.  Same console messages as the reference."""
+    path = conf["paths"]["ckpt_model_path"]
+    want = len(conf["classes"])
+    print("\n" + _BAR)
+    try:
+        if not (path and os.path.isfile(path)):
+            return _fail("Invalid checkpoint file path.", exit_on_fail)
+        sd = _state_dict_of(path)
+        if sd is None:
+            return _fail("Invalid file extension.", exit_on_fail)
+        have = next((v.shape[0] for k, v in sd.items() if "classifier.weight" in k or "criterion.weight" in k), None)
+        if have == want:
             print("--------------- Loaded model weights from checkpoint with matching number of classes. ---------------")
         else:
-            print(f"Number of classes in checkpoint ({ckpt_num_classes}) does not match the current number of classes "
-                  f"({num_classes}). Proceeding with modifications.")
-            ignored_layers = [k for k, v in state_dict.items() if k in model_state_dict and v.shape != model_state_dict[k].shape]
-            ignored_layers = [i for i in ignored_layers if any(x in i for x in ["head", "criterion"])]
-            for k in ignored_layers:
+            print(f"Number of classes in checkpoint ({have}) does not match the current number of classes ({want}). "
+                  "Proceeding with modifications.")
+            own = seg_module.state_dict()
+            for k in [k for k, v in sd.items() if k in own and v.shape != own[k].shape and ("head" in k or "criterion" in k)]:
+                old_shape = sd[k].shape
+                sd[k] = (torch.FloatTensor([c[0] for c in conf["classes"].values()]) if "criterion" in k
+                         else torch.zeros_like(sd[k][:want]))
                 print("-", k, "has been modified.")
-                print(state_dict[k].shape, "  ->  ", flush=True, end="")
-                if "criterion" in k:
-                    state_dict[k] = torch.FloatTensor([conf["classes"][i][0] for i in conf["classes"]])
-                else:
-                    state_dict[k] = 0 * torch.abs(state_dict[k][0:num_classes])
-                print(state_dict[k].shape)
-            seg_module.load_state_dict(state_dict, strict=False)
-        print("###############################################################")
-    else:
-        print("Invalid checkpoint file path.")
-        if exit_on_fail:
-            raise SystemExit()
-        print("###############################################################")
-    print()
+                print(old_shape, "  ->  ", sd[k].shape)
+        seg_module.load_state_dict(sd, strict=False)
+    finally:
+        print(_BAR + "\n")
 
 
 def get_module(checkpoint):
-    if checkpoint is not None and os.path.isfile(checkpoint):
-        weights = _read(checkpoint)
-        if str(checkpoint).endswith(".ckpt"):
-            weights = weights["state_dict"]
-    else:
+    """zone_detect/model.py:61-79: the bare segmentation model's tensors out of a ``.ckpt`` / ``.pth`` — keys of a Lightning
+    module (``model.seg_model.<name>``) lose that prefix, everything else of such a file (criterion, metadata MLP) is dropped."""
+    if checkpoint is None or not os.path.isfile(checkpoint):
         print('Error with checkpoint provided: either a .ckpt with a "state_dict" key or an OrderedDict pt/pth file')
         return {}
-    if "model.seg_model" in list(weights.keys())[0]:
-        weights = {k.partition("model.seg_model.")[2]: v for k, v in weights.items()}
-        weights = {k: v for k, v in weights.items() if k != ""}
+    weights = _read(checkpoint)
+    if str(checkpoint).endswith(".ckpt"):
+        weights = weights["state_dict"]
+    prefix = "model.seg_model."
+    if prefix[:-1] in next(iter(weights)):
+        weights = {k.partition(prefix)[2]: v for k, v in weights.items() if k.partition(prefix)[2]}
     return weights
 
 
