@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "flair_amd")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libflair_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_halo.hip", "conv_hg.hip", "wgrad.hip", "wgrad_halo.hip", "wgrad_hg.hip", "stem.hip", "batchnorm.hip", "misc.hip", "ce_head.hip", "feed.hip", "unet.hip", "capi.hip", "prof.hip", "tune.hip", "metadata_mlp.hip"]
+SOURCES = ["conv_igemm.hip", "conv_halo.hip", "conv_hg.hip", "wgrad.hip", "wgrad_halo.hip", "wgrad_hg.hip", "stem.hip", "batchnorm.hip", "misc.hip", "ce_head.hip", "feed.hip", "unet.hip", "capi.hip", "prof.hip", "tune.hip", "metadata_mlp.hip", "segformer_ops.hip", "segformer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("FLAIR_STAMPS") == "1":   # diagnostic build: phase stamps in the halo-GEMM kernel (scripts/stamp_hg.py)
     FLAGS.append("-DFLAIR_HG_STAMPS")

@@ -4,12 +4,17 @@
 
 #include "../../include/flair_hip.h"
 #include "unet.h"
+#include "segformer.h"
 
 using namespace flair;
 
 namespace flair { int conv_weight_rows_pad(int cout); }
 
 struct flair_unet { UNet net; flair_unet(int a, int b, int c) : net(a, b, c) {} };
+struct flair_segformer {
+  SegFormer net;
+  flair_segformer(int a, int b, const int* d, const int* h, const int* hd, const int* sr, int dh, int dt) : net(a, b, d, h, hd, sr, dh, dt) {}
+};
 
 extern "C" {
 
@@ -374,6 +379,45 @@ int flair_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, 
 }
 int flair_nhwc_to_nchw(int dtype, const void* x, float* y, int N, int C, int H, int W, int Cpad, void* stream) {
   return nhwc_to_nchw_f32(dtype, x, y, N, C, H, W, Cpad, nullptr, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------ SegFormer (zone_detect, HuggingFace provider)
+int flair_segformer_create(flair_segformer_t** out, int in_channels, int num_labels, const int depths[4], const int hidden_sizes[4],
+                           const int num_heads[4], const int sr_ratios[4], int decoder_hidden_size, int dtype) {
+  if (!out || !depths || !hidden_sizes || !num_heads || !sr_ratios || in_channels < 1 || num_labels < 1) return -1;
+  if (dtype != DT_F32 && dtype != DT_BF16) return -2;
+  for (int i = 0; i < 4; ++i)
+    if (depths[i] < 1 || hidden_sizes[i] < 64 || (hidden_sizes[i] % 64) || num_heads[i] < 1 || hidden_sizes[i] != 64 * num_heads[i] ||
+        sr_ratios[i] != (8 >> i))
+      return -2;   // MiT-B1 .. B5 geometry: heads of 64 channels, reduction ratios 8 / 4 / 2 / 1
+  if (decoder_hidden_size < 64 || (decoder_hidden_size % 64)) return -2;
+  flair_segformer* h = new (std::nothrow) flair_segformer(in_channels, num_labels, depths, hidden_sizes, num_heads, sr_ratios,
+                                                          decoder_hidden_size, dtype);
+  if (!h) return -100;
+  *out = h;
+  return 0;
+}
+void flair_segformer_destroy(flair_segformer_t* h) { delete h; }
+int64_t flair_segformer_param_count(const flair_segformer_t* h) { return h ? h->net.n_params : -1; }
+int flair_segformer_num_tensors(const flair_segformer_t* h) { return h ? (int)h->net.tensors.size() : -1; }
+int flair_segformer_tensor_info(const flair_segformer_t* h, int i, char* name, int name_cap, int64_t shape[4], int* ndim, int64_t* offset,
+                                int* kind) {
+  if (!h || i < 0 || i >= (int)h->net.tensors.size() || !name || name_cap < 2) return -1;
+  const SfTensor& t = h->net.tensors[i];
+  strncpy(name, t.name.c_str(), name_cap - 1);
+  name[name_cap - 1] = 0;
+  for (int d = 0; d < 4; ++d) shape[d] = t.shape[d];
+  *ndim = t.ndim; *offset = t.offset; *kind = t.kind;
+  return 0;
+}
+int64_t flair_segformer_workspace_bytes(flair_segformer_t* h, int B, int H, int W) {
+  if (!h || B < 1 || !h->net.shape_ok(H, W)) return -1;
+  return (int64_t)h->net.workspace_bytes(B, H, W);
+}
+int flair_segformer_forward(flair_segformer_t* h, const float* params, const float* x_nchw, float* logits_quarter_nchw,
+                            float* logits_full_nchw, int B, int H, int W, void* ws, size_t wsb, void* stream) {
+  if (!h) return -1;
+  return h->net.forward(params, x_nchw, logits_quarter_nchw, logits_full_nchw, B, H, W, ws, wsb, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -120,8 +120,15 @@ class FLAIR_ModelFactory(nn.Module):
             self.seg_model = create_model(arch=architecture, encoder_name=encoder, classes=n_classes,
                                           in_channels=n_channels, **kw)
         elif self.model_provider == "HuggingFace":
-            raise NotImplementedError("flair_amd covers the SegmentationModelsPytorch U-Net/ResNet34 hot path only "
-                                      "(HuggingFace models are out of scope, SURVEY.md §8f row f3)")
+            # model.py:43-50: AutoModelForSemanticSegmentation.from_pretrained(org_model, num_labels=...).  No hub here: the
+            # SegFormer family (BASELINE config 5) is built natively from its published geometry, weights arrive through
+            # load_state_dict; anything else raises.  Inference only.
+            from .segformer import SegformerForSemanticSegmentation, config_for
+            hf = config["model_framework"]["HuggingFace"]
+            kw = config_for(hf["org_model"])
+            kw.update({k: hf[k] for k in ("depths", "decoder_hidden_size") if k in hf})
+            self.seg_model = SegformerForSemanticSegmentation(num_channels=n_channels, num_labels=n_classes,
+                                                              compute_dtype=compute_dtype, **kw)
 
     def forward(self, x, met=None):
         if self.use_metadata == True and self.model_provider == "SegmentationModelsPytorch":  # noqa: E712
@@ -133,6 +140,8 @@ class FLAIR_ModelFactory(nn.Module):
             feats[-1] = _AddRowVec.apply(feats[-1], x_enc)
             output = self.seg_model.decoder(*feats)
             output = self.seg_model.segmentation_head(output)
+        elif self.model_provider == "HuggingFace":
+            output = self.seg_model(x).logits   # model.py:66-68
         else:
             output = self.seg_model(x)
         return output

@@ -165,7 +165,13 @@ class ZoneDetector:
                 L.check(L.lib().flair_detect_stitch_preds(L.ptr(preds), L.ptr(prob), B, self.S, self.margin, L.ptr(tiles), L.ptr(out),
                                                           Hr, Wr, L.stream()), "flair_detect_stitch_preds")
                 continue
-            logits = self.model(imgs).float().contiguous()
+            if hasattr(self.model, "forward_full"):
+                # HuggingFace provider (SegFormer): `.logits` come at 1/4 of the tile size, which neither the margin crop nor
+                # convert (compare.py:69-82) rescale; the x4 bilinear upsample (align_corners=False) the library itself applies
+                # in front of its loss brings them to tile resolution first
+                logits = self.model.forward_full(imgs)
+            else:
+                logits = self.model(imgs).float().contiguous()
             if logits.shape[1] != self.n_classes:
                 raise RuntimeError(f"model returned {logits.shape[1]} classes, config says {self.n_classes}")
             L.check(L.lib().flair_detect_stitch(L.ptr(logits), B, self.n_classes, self.S, self.margin, mode, L.ptr(tiles),

@@ -224,6 +224,31 @@ int flair_profile_stop(void);
 int flair_profile_kernel(int i, char* name, int name_cap, double* total_ms, int64_t* launches, double* flops,
                          double* bytes);
 
+/* ------------------------------------------------------------------------------------------------
+ * SegFormer (MiT encoder + all-MLP decode head), inference only: the HuggingFace provider of zone_detect —
+ * /root/reference/src/zone_detect/model.py:42-50 (AutoModelForSemanticSegmentation.from_pretrained) and
+ * compare.py:31-36 (`model(imgs).logits`); BASELINE config 5 names SegFormer-MiT-B2 with 5 input channels.
+ * Replaces transformers' SegformerForSemanticSegmentation.forward in eval mode.  Tensor names / shapes
+ * (flair_segformer_tensor_info) are that library's state_dict keys; every tensor, BatchNorm running
+ * statistics included (kind 1), lives in ONE flat fp32 buffer.  Geometry: MiT-B1..B5 (heads of 64 channels,
+ * reduction ratios 8/4/2/1); H, W multiples of 32 with (H/32)*(W/32) a multiple of 16 and <= 256. */
+typedef struct flair_segformer flair_segformer_t;
+int flair_segformer_create(flair_segformer_t** out, int in_channels, int num_labels, const int depths[4],
+                           const int hidden_sizes[4], const int num_heads[4], const int sr_ratios[4],
+                           int decoder_hidden_size, int dtype);
+void flair_segformer_destroy(flair_segformer_t* h);
+int64_t flair_segformer_param_count(const flair_segformer_t* h);
+int flair_segformer_num_tensors(const flair_segformer_t* h);
+int flair_segformer_tensor_info(const flair_segformer_t* h, int i, char* name, int name_cap, int64_t shape[4], int* ndim,
+                                int64_t* offset, int* kind);
+int64_t flair_segformer_workspace_bytes(flair_segformer_t* h, int B, int H, int W);
+/* logits_quarter_nchw: fp32 (B, labels, H/4, W/4) = the library's `.logits`; logits_full_nchw: the same after
+ * nn.functional.interpolate(size=(H, W), mode="bilinear", align_corners=False), what softmax / margin crop /
+ * convert (compare.py:35, 69-82) need at tile resolution.  Either may be NULL, not both. */
+int flair_segformer_forward(flair_segformer_t* h, const float* params, const float* x_nchw, float* logits_quarter_nchw,
+                            float* logits_full_nchw, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* Diagnostic tuning switch (kernel-variant A/B timing inside one process; keys are the FLAIR_* environment
  * variables DESIGN.md lists, the environment supplies the default).  Returns 0. */
 int flair_tune_set(const char* key, int value);

@@ -1,0 +1,125 @@
+"""SegFormer (MiT-B2, 5 channels, 19 labels: BASELINE config 5) on the HIP executor against the oracle — transformers'
+SegformerForSemanticSegmentation on the CPU in fp32 (oracle/segformer.py; parity unpinned against the reference, which holds
+nothing for this path) — through the C ABI (flair_segformer_forward).  north_star tolerances: logits within 1e-3 in fp32,
+masks by the one parity rule (zero mismatches where the oracle's top-2 probability gap exceeds 1e-5)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(dev, dtype="f32", labels=19, seed=2022, **geom):
+    import flair_amd
+    from oracle import segformer as osf
+    ref = osf.seeded_model(5, labels, seed=seed, **geom)
+    kw = {k: geom[k] for k in ("depths", "decoder_hidden_size") if k in geom}
+    hip = flair_amd.SegformerForSemanticSegmentation(num_channels=5, num_labels=labels, compute_dtype=dtype, **kw)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    return ref, hip.to(dev)
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 128), (2, 256, 128), (1, 512, 512)])
+def test_logits_and_masks_match_transformers_fp32(dev, shape):
+    from oracle import parity
+    from oracle import segformer as osf
+    ref, hip = _pair(dev)
+    x = torch.randn(shape[0], 5, shape[1], shape[2], generator=torch.Generator().manual_seed(3))
+    lq, lf = osf.logits(ref, x)
+    out = hip(x.to(dev))
+    gq = out.logits.cpu()
+    gf = hip.forward_full(x.to(dev)).cpu()
+    assert gq.shape == lq.shape == (shape[0], 19, shape[1] // 4, shape[2] // 4) and gf.shape == lf.shape
+    assert float((gq - lq).abs().max()) < 1e-3 and float((gf - lf).abs().max()) < 1e-3
+    assert float((gq - lq).abs().max()) < 5e-5   # measured 6e-6: exact-fp32 MFMA chains against MKL's blocking
+    parity.assert_mask_parity(f"segformer_b2_{shape[0]}x{shape[1]}x{shape[2]}", lf.argmax(1).numpy(), gf.argmax(1).numpy(),
+                              parity.top2_gap(lf.numpy()), logits_ref=lf.numpy(), logits_hip=gf.numpy())
+
+
+def test_golden_fixture_and_other_geometry(dev, golden_dir):
+    """The committed fixture (made from the oracle by tests/golden/make_golden_segformer.py) and a second geometry, MiT-B1
+    (depths 2-2-2-2, decode width 256, 13 labels): the executor follows the layer table, not one hard-wired network."""
+    from oracle import segformer as osf
+    g = np.load(os.path.join(golden_dir, "segformer_b2_c19.npz"))
+    _, hip = _pair(dev, seed=int(g["model_seed"]))
+    x = torch.randn(1, 5, 256, 256, generator=torch.Generator().manual_seed(int(g["tile_seed"])))
+    lq = hip(x.to(dev)).logits.cpu()
+    lf = hip.forward_full(x.to(dev)).cpu()
+    assert np.abs(lq[0, :, 24:40, 24:40].numpy() - g["logits_quarter_crop"]).max() < 1e-3
+    assert np.abs(lq.double().mean(dim=(0, 2, 3)).numpy() - g["logits_quarter_mean"]).max() < 1e-4
+    assert np.abs(lf[0, :, 100:132, 100:132].numpy() - g["logits_full_crop"]).max() < 1e-3
+    assert float((lf.argmax(1).numpy().astype(np.uint8) != g["mask"]).mean()) < 1e-4   # exact ties only (rule: test above)
+    ref, hip1 = _pair(dev, labels=13, seed=5, depths=[2, 2, 2, 2], decoder_hidden_size=256)
+    x = torch.randn(2, 5, 128, 128, generator=torch.Generator().manual_seed(4))
+    assert float((hip1(x.to(dev)).logits.cpu() - osf.logits(ref, x)[0]).abs().max()) < 5e-5
+
+
+def test_bf16_mode_tracks_the_oracle(dev):
+    """bf16 throughput mode: the logit-error rule of oracle/parity.py (measured: max |dlogit| 1.0e-2 and rms 1.9e-3 of the
+    logit scale at 512x512, profiles/r3_parity.json; bounds 3x)."""
+    from oracle import parity
+    from oracle import segformer as osf
+    ref, hip = _pair(dev, "bf16")
+    x = torch.randn(1, 5, 512, 512, generator=torch.Generator().manual_seed(3))
+    _, lf = osf.logits(ref, x)
+    gf = hip.forward_full(x.to(dev)).cpu()
+    parity.assert_masks_within_logit_error("segformer_b2_bf16_1x512", lf.numpy(), gf.numpy(), gf.argmax(1).numpy(),
+                                           max_rel_dlogit=3e-2, max_rel_rms=6e-3)
+
+
+def test_contract(dev):
+    import flair_amd
+    from flair_amd._lib import FlairHipError
+    m = flair_amd.SegformerForSemanticSegmentation(num_channels=5, num_labels=19, depths=(1, 1, 1, 1))
+    with pytest.raises(FlairHipError):
+        m(torch.zeros(1, 5, 128, 128))                  # host tensors are refused: no CPU fallback
+    m = m.to(dev)
+    with pytest.raises(RuntimeError, match="multiples of 32"):
+        m(torch.zeros(1, 5, 96, 96, device=dev))        # (3 x 3 = 9 reduced tokens: not a whole 16-key tile)
+    with pytest.raises(RuntimeError):
+        m.train()
+    assert m(torch.zeros(2, 5, 128, 128, device=dev)).logits.shape == (2, 19, 32, 32)
+    # the factory's HuggingFace provider (model.py:43-50, 66-68)
+    cfg = {"model_framework": {"model_provider": "HuggingFace", "HuggingFace": {"org_model": "nvidia/mit-b2"}},
+           "use_metadata": False, "channels": [1, 2, 3, 4, 5], "classes": {i: [1, str(i)] for i in range(1, 20)}}
+    f = flair_amd.FLAIR_ModelFactory(cfg).to(dev)
+    assert f(torch.zeros(1, 5, 128, 128, device=dev)).shape == (1, 19, 32, 32)
+    with pytest.raises(NotImplementedError):
+        flair_amd.FLAIR_ModelFactory({**cfg, "model_framework": {"model_provider": "HuggingFace",
+                                                                 "HuggingFace": {"org_model": "openmmlab/upernet-swin-small"}}})
+
+
+def test_zone_detector_with_segformer_matches_sequential_replay(dev):
+    """zone_detect's window loop (slicing -> model -> softmax -> margin crop -> convert -> write, compare.py:20-39,69-82) with
+    the HuggingFace provider, on a raster that is not a multiple of the stride: the device pipeline against the sequential CPU
+    restatement (oracle/zone_detect.py) fed the oracle's logits upsampled x4 to the tile size."""
+    from flair_amd.zone_detect import ZoneDetector
+    from oracle import parity
+    from oracle import segformer as osf
+    from oracle import zone_detect as oz
+    ref, hip = _pair(dev, depths=[1, 1, 1, 1], decoder_hidden_size=256)
+
+    class _Upsampled:   # what compare.py needs from a model whose logits come at 1/4 resolution
+        def eval(self):
+            return self
+
+        def __call__(self, x):
+            return osf.logits(ref, x)[1]
+
+    cfg = {"img_pixels_detection": 128, "margin": 32, "output_type": "argmax", "n_classes": 19, "batch_size": 3,
+           "channels": [1, 2, 3, 4, 5], "norma_task": [{"norm_type": "custom", "norm_means": [105.08, 110.87, 101.82, 106.38, 53.26],
+                                                      "norm_stds": [52.17, 45.38, 44, 39.69, 79.3]}]}
+    raster = np.random.default_rng(4).integers(0, 256, size=(5, 200, 264), dtype=np.uint8)
+    gap = np.zeros((200, 264))
+    want = oz.detect_raster_np(_Upsampled(), raster, cfg, gap_out=gap)
+    got = ZoneDetector(hip, cfg).run(torch.from_numpy(raster).to(dev)).cpu().numpy()
+    assert got.shape == want.shape == (2, 200, 264)
+    parity.assert_mask_parity("zone_detector_segformer_200x264", want[0], got[0], gap)
+    assert np.abs(got[1] - want[1]).max() < 1e-4
+    cfg2 = dict(cfg, output_type="class_prob", batch_size=5)
+    want = oz.detect_raster_np(_Upsampled(), raster, cfg2)
+    got = ZoneDetector(hip, cfg2).run(torch.from_numpy(raster).to(dev)).cpu().numpy()
+    assert got.shape == (19, 200, 264) and got.dtype == np.uint8
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1

@@ -205,3 +205,20 @@ def test_bench_multi_gpu_request_without_gpus_fails_cleanly():
                        capture_output=True, text=True, timeout=300, env=env)
     if torch.cuda.device_count() < 2:
         assert r.returncode == 2 and "GPU(s) are visible" in r.stderr
+
+
+def test_segformer_state_dict_is_the_librarys():
+    """flair_amd.SegformerForSemanticSegmentation (parameter containers only, no compute on the CPU) carries exactly the keys,
+    order and shapes of transformers' SegformerForSemanticSegmentation for MiT-B2 / 5 channels / 19 labels (BASELINE config 5),
+    so the library's checkpoints load strictly; 27 367 507 parameters."""
+    import flair_amd
+    from oracle import segformer as osf
+    hf = osf.seeded_model(5, 19, seed=0)
+    m = flair_amd.SegformerForSemanticSegmentation(num_channels=5, num_labels=19)
+    a, b = hf.state_dict(), m.state_dict()
+    assert list(a.keys()) == list(b.keys()) and len(a) == 380
+    assert all(a[k].shape == b[k].shape and a[k].dtype == b[k].dtype for k in a)
+    m.load_state_dict(a, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == sum(p.numel() for p in hf.parameters()) == 27_367_507
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 5, 128, 128))   # host tensors: no CPU fallback
