@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include "segformer_ops.h"
+#include "tune.h"
 
 namespace flair {
 
@@ -174,8 +175,6 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
   void* xin = alloc((size_t)B * H * W * Cin_p * es);
   SF_RUN(nchw_f32_to_nhwc(dtype, x_nchw, xin, B, in_channels, H, W, Cin_p, s_));
   const int H4 = H / 4, W4 = W / 4;
-  const int cat_ld = 4 * dec_hidden;
-  void* cat = alloc((size_t)B * H4 * W4 * cat_ld * es);
   void* feat[4];
   int fh[4], fw[4];
   for (int i = 0; i < 4; ++i) {
@@ -227,21 +226,71 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
     top_ = mark;   // the stage's scratch is free again (one stream: later launches are ordered behind its readers)
     sin = feat[i]; sH = Hs; sW = Ws;
   }
-  // ---- decode head: Linear to dec_hidden per stage, bilinear upsample to 1/4 resolution, concatenation in REVERSED stage order
-  for (int i = 0; i < 4; ++i) {
-    unsigned char* slot = (unsigned char*)cat + (size_t)(3 - i) * dec_hidden * es;
-    if (i == 0) {   // already at 1/4 resolution: straight into its channel slice
-      gemm(lins[dec_proj[0]], feat[0], B, fh[0], fw[0], slot, cat_ld, nullptr, nullptr, nullptr, 0, nullptr);
-    } else {
-      const size_t mark = top_;
-      void* p = alloc((size_t)B * fh[i] * fw[i] * dec_hidden * es);
-      gemm(lins[dec_proj[i]], feat[i], B, fh[i], fw[i], p, dec_hidden, nullptr, nullptr, nullptr, 0, nullptr);
-      SF_RUN(sf_bilinear_nhwc(dtype, p, slot, B, fh[i], fw[i], dec_hidden, H4, W4, cat_ld, s_));
-      top_ = mark;
-    }
-  }
+  // ---- decode head.  The library's order (Linear to D per stage, upsample, concatenate stage 3 .. 0, 1x1 fuse over 4 D channels,
+  // BatchNorm, ReLU) restructured by linearity (segformer_ops.hip, 'decode-head helpers'): per stage  g_i = (F_i P_i) f_i  at the
+  // stage's own resolution, then  z = relu(bn(g_0 + up(g_1) + up(g_2) + up(g_3) + F [b_3 | b_2 | b_1 | b_0])).
+  // FLAIR_SF_HEAD=0 runs the library's order (A/B and parity of the restructuring itself).
   void* z = alloc((size_t)B * H4 * W4 * dec_hidden * es);
-  gemm(lins[fuse], cat, B, H4, W4, z, dec_hidden, nullptr, bn_scale, bn_shift, 1, nullptr);   // 1x1 conv + folded BatchNorm + ReLU
+  const int D = dec_hidden;
+  const SfLin& Lf = lins[fuse];
+  if (tune("FLAIR_SF_HEAD", 1)) {
+    float* shift2 = (float*)alloc((size_t)D * 4);
+    SF_RUN(sf_fuse_bias(params_ + Lf.w_off, D, params_ + lins[dec_proj[3]].b_off, params_ + lins[dec_proj[2]].b_off,
+                        params_ + lins[dec_proj[1]].b_off, params_ + lins[dec_proj[0]].b_off, bn_scale, bn_shift, shift2, s_));
+    void* g[4];
+    const int kstep = dtype == DT_F32 ? 32 : 64;
+    for (int i = 0; i < 4; ++i) {
+      const SfLin& Lp = lins[dec_proj[i]];
+      const int Ci = Lp.cin;
+      // P_i transposed, packed as the weight of a product over D: rows = the C_i input channels, K = D
+      const size_t pt_off = top_;
+      const int pt_rows = conv_weight_rows_pad(Ci), pt_kpad = (int)round_up(D, kstep);
+      alloc((size_t)pt_rows * pt_kpad * es);
+      PackTable tb;
+      memset(&tb, 0, sizeof(tb));
+      tb.n = 1;
+      PackDesc& d = tb.d[0];
+      d.w_off = Lp.w_off; d.dst_off = pt_off; d.Cout = D; d.Cin = Ci; d.R = 1; d.S = 1; d.Cin_p = D; d.rows_pad = pt_rows; d.Kpad = pt_kpad; d.tf = 1;
+      SF_RUN(pack_weights_all(dtype, params_, base_, tb, s_));
+      // F_i = columns [(3 - i) D, (4 - i) D) of the fuse weight, as a [D pixels][D channels] tensor
+      void* fi = alloc((size_t)D * D * es);
+      SF_RUN(sf_slice_cols(dtype, params_ + Lf.w_off, 4 * D, (3 - i) * D, D, D, fi, s_));
+      // W_i = F_i P_i: [D][C_i], exactly the packed layout of a C_i -> D product (K = C_i is a whole number of K steps)
+      void* wi = alloc((size_t)conv_weight_rows_pad(D) * round_up(Ci, kstep) * es);
+      {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.src0 = fi; a.C0 = D; a.N = 1; a.Hin = D; a.Win = 1; a.Hout = D; a.Wout = 1; a.R = 1; a.S = 1; a.out_mul = 1; a.in_div = 1;
+        a.Cout = Ci; a.Kg = D; a.Kpad = pt_kpad; a.w = base_ + pt_off; a.out = wi; a.out_ld = (int)round_up(Ci, kstep);
+        SF_RUN(launch_conv(dtype, a, s_));
+      }
+      g[i] = alloc((size_t)B * fh[i] * fw[i] * D * es);
+      {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.src0 = feat[i]; a.C0 = Ci; a.N = B; a.Hin = fh[i]; a.Win = fw[i]; a.Hout = fh[i]; a.Wout = fw[i]; a.R = 1; a.S = 1; a.out_mul = 1;
+        a.in_div = 1; a.Cout = D; a.Kg = Ci; a.Kpad = (int)round_up(Ci, kstep); a.w = wi; a.out = g[i]; a.out_ld = D;
+        SF_RUN(launch_conv(dtype, a, s_));
+      }
+    }
+    SF_RUN(sf_upsample_sum_bn_relu(dtype, g[0], g[1], g[2], g[3], bn_scale, shift2, z, B, H4, W4, D, s_));
+  } else {
+    const int cat_ld = 4 * dec_hidden;
+    void* cat = alloc((size_t)B * H4 * W4 * cat_ld * es);
+    for (int i = 0; i < 4; ++i) {
+      unsigned char* slot = (unsigned char*)cat + (size_t)(3 - i) * dec_hidden * es;
+      if (i == 0) {   // already at 1/4 resolution: straight into its channel slice
+        gemm(lins[dec_proj[0]], feat[0], B, fh[0], fw[0], slot, cat_ld, nullptr, nullptr, nullptr, 0, nullptr);
+      } else {
+        const size_t mark = top_;
+        void* p = alloc((size_t)B * fh[i] * fw[i] * dec_hidden * es);
+        gemm(lins[dec_proj[i]], feat[i], B, fh[i], fw[i], p, dec_hidden, nullptr, nullptr, nullptr, 0, nullptr);
+        SF_RUN(sf_bilinear_nhwc(dtype, p, slot, B, fh[i], fw[i], dec_hidden, H4, W4, cat_ld, s_));
+        top_ = mark;
+      }
+    }
+    gemm(lins[fuse], cat, B, H4, W4, z, dec_hidden, nullptr, bn_scale, bn_shift, 1, nullptr);   // 1x1 conv + folded BatchNorm + ReLU
+  }
   float* lq = logits_quarter ? logits_quarter : (float*)alloc((size_t)B * num_labels * H4 * W4 * 4);
   gemm(lins[cls], z, B, H4, W4, nullptr, 0, nullptr, nullptr, nullptr, 0, lq);   // classifier: fp32 NCHW logits at 1/4 resolution
   if (logits_full) SF_RUN(sf_bilinear_nchw_f32(lq, logits_full, (long)B * num_labels, H4, W4, H, W, s_));

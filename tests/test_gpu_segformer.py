@@ -56,6 +56,25 @@ def test_golden_fixture_and_other_geometry(dev, golden_dir):
     assert float((hip1(x.to(dev)).logits.cpu() - osf.logits(ref, x)[0]).abs().max()) < 5e-5
 
 
+def test_restructured_decode_head_equals_the_librarys_order(dev):
+    """The decode head runs its products at each stage's own resolution with pre-multiplied weights (linearity: a per-channel
+    bilinear resize commutes with a per-pixel channel mix; csrc/segformer_ops.hip).  FLAIR_SF_HEAD=0 runs the library's order
+    (Linear, upsample, concatenate, 1x1 fuse): same logits up to fp32 summation order, and both sit on the oracle."""
+    from flair_amd import _lib as L
+    from oracle import segformer as osf
+    ref, hip = _pair(dev)
+    x = torch.randn(2, 5, 256, 256, generator=torch.Generator().manual_seed(9))
+    want = osf.logits(ref, x)[0]
+    try:
+        L.check(L.lib().flair_tune_set(b"FLAIR_SF_HEAD", 0))
+        a = hip(x.to(dev)).logits.cpu()
+    finally:
+        L.lib().flair_tune_set(b"FLAIR_SF_HEAD", 1)
+    b = hip(x.to(dev)).logits.cpu()
+    assert float((a - b).abs().max()) < 2e-5
+    assert float((a - want).abs().max()) < 5e-5 and float((b - want).abs().max()) < 5e-5
+
+
 def test_bf16_mode_tracks_the_oracle(dev):
     """bf16 throughput mode: the logit-error rule of oracle/parity.py (measured: max |dlogit| 1.0e-2 and rms 1.9e-3 of the
     logit scale at 512x512, profiles/r3_parity.json; bounds 3x)."""
