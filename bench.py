@@ -57,7 +57,7 @@ def collect_profile(L):
     return sorted(out, key=lambda r: -r["ms"])
 
 
-PMC_FILE = "profiles/r2_pmc_traffic.json"
+PMC_FILE = "profiles/r3_pmc_traffic.json"
 
 
 def pmc_traffic(kernel):

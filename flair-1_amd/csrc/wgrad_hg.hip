@@ -411,74 +411,9 @@ __global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(const float* __re
   }
 }
 
-// Round 3: the same ordered sum, one workgroup (9 waves) per slab block = all nine taps of a 16 (cout) x 16 (cin) tile of the
-// gradient.  The kernel above wrote every sum as four 4-byte stores 36 bytes apart (OIHW keeps a filter's nine taps together,
-// the slab keeps them 1 KiB apart): 2.4-9.4 MB of scattered stores per launch, and its many-slab flavour read 256-byte pieces
-// of 64-128 slabs.  Here a thread sums ALL slabs of its element (four partial sums in flight, order fixed: x = 0, 4, 8 ... |
-// 1, 5 ... | 2 ... | 3 ..., then ((s0 + s1) + (s2 + s3))), the block is transposed through LDS and leaves as 16 runs of 576
-// contiguous bytes.  Reads stay 1 KiB-contiguous per wave and slab.
-template <int CH, int KG>
-__global__ __launch_bounds__(576) void wgrad_big_reduce_t_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit,
-                                                                 int ny, int nz, int Cin_real, int accumulate) {
-  constexpr int CK = 8 * CH, CO = 16 * CH / KG, WK = 4 / KG, COT = CO / WK / 16, CIT = CK / 2 / 16;
-  constexpr int BLK4 = CO * 9 * CK / 4;   // float4 elements per slab
-  constexpr int NBLK = BLK4 / 576;        // 16 x 16 x 9 blocks per slab = wave slots x COT x CIT
-  constexpr int ROW = 148;                // floats per cout row of the transposed block (144 used)
-  __shared__ __attribute__((aligned(16))) float sh[16 * ROW];
-  const int t = threadIdx.x;
-  const long xs = (long)ny * nz * BLK4;
-  for (int blk = blockIdx.x; blk < ny * nz * NBLK; blk += gridDim.x) {
-    const int yz = blk / NBLK, b = blk - yz * NBLK;
-    const float4* p = reinterpret_cast<const float4*>(part) + (long)yz * BLK4 + (long)b * 576 + t;
-    float4 s[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int x = 0;
-    for (; x + 3 < nsplit; x += 4) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = p[(long)(x + q) * xs];
-        s[q].x += v.x; s[q].y += v.y; s[q].z += v.z; s[q].w += v.w;
-      }
-    }
-    for (int q = 0; x < nsplit; ++x, ++q) {
-      const float4 v = p[(long)x * xs];
-      s[q].x += v.x; s[q].y += v.y; s[q].z += v.z; s[q].w += v.w;
-    }
-    const float r[4] = {(s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
-                        (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w)};
-    // element t of the block = (tap, lane): cin lr, cout 4 * lq + k4
-    const int tp = t >> 6, lane = t & 63, lr = lane & 15, lq = lane >> 4;
-    __syncthreads();   // the previous block's rows have left
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) sh[(lq * 4 + k4) * ROW + lr * 9 + tp] = r[k4];
-    __syncthreads();
-    // block b = (wslot * COT + co) * CIT + ci, wslot = wc * WK + wk
-    int q = b;
-    const int ci = q % CIT; q /= CIT;
-    const int co = q % COT; q /= COT;
-    const int wk = q % WK, wc = q / WK;
-    const int z = yz % nz, y = yz / nz;
-    const int c0 = y * CK + (wc * CIT + ci) * 16, k0 = z * CO + (wk * COT + co) * 16;
-    const int k = t / 36, j = t - k * 36;   // 16 rows x 36 float4
-    float* d = dw + ((long)(k0 + k) * Cin_real + c0) * 9 + j * 4;
-    float4 v = *reinterpret_cast<const float4*>(sh + k * ROW + j * 4);
-    if (accumulate) {
-      const float4 o = *reinterpret_cast<const float4*>(d);
-      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-    }
-    *reinterpret_cast<float4*>(d) = v;
-  }
-}
-
 template <int CH, int KG>
 static void launch_big_reduce(const float* part, float* dw, int nsplit, int ny, int nz, long total4, int Cin_real, int accumulate,
                               hipStream_t s) {
-  if (tune("FLAIR_WG_REDUCE_T", 1) && (Cin_real % 16) == 0 && Cin_real == ny * 8 * CH) {   // whole 16-channel blocks, no padded input channels
-    constexpr int NBLK = (16 * CH / KG) * 9 * (8 * CH) / 4 / 576;
-    hipLaunchKernelGGL((wgrad_big_reduce_t_kernel<CH, KG>), dim3(ny * nz * NBLK), dim3(576), 0, s, part, dw, nsplit, ny, nz, Cin_real, accumulate);
-    return;
-  }
   if (nsplit >= 64) {
     int blocks = cdiv(total4, 16);
     if (blocks > 8192) blocks = 8192;
