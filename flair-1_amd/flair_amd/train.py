@@ -170,10 +170,7 @@ class SegTrainer:
 
     def _predict(self, m, img, B, H, W):
         preds = torch.empty(B, H, W, dtype=torch.uint8, device=img.device)
-        l = L.lib()
-        he = m._hh(False)   # eval forwards run on their own executor
         # the argmax comes out of the head convolution's epilogue (or, for shapes its persistent kernel does not take, from the
         # separate pass over the NHWC logits inside the same native call): the logits never reach HBM
-        L.check(l.flair_unet_want_preds(he, L.ptr(preds), None), "flair_unet_want_preds")
-        m._c_forward(img, training=False, want_logits=False)
+        m._c_forward(img, training=False, want_logits=False, preds=preds)
         return preds

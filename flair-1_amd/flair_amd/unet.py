@@ -432,15 +432,61 @@ class Unet(nn.Module):
         """num_batches_tracked += 1 for BatchNorm layers [lo, hi) (one op on the flat int64 buffer)."""
         self._flat_n[lo:hi] += 1
 
+    # eval forwards of small batches are launch-bound (~150 kernels of a few microseconds: predict_step at the reference's
+    # batch size 1, data_module.py:100, ran at 870 tiles/s against 10 000 at batch 32): the third identical call — same weights,
+    # shape, workspace and requested outputs — is captured into a HIP graph and replayed from then on (FLAIR_EVAL_GRAPH=0: never)
+    _GRAPH_MAX_PIXELS = 4 * 512 * 512
+
+    def _eval_graph(self, gkey, x, want_logits, preds, prob, ws, h):
+        ent = self._eval_graphs.get(gkey)
+        if ent is None:
+            B, _, H, W = x.shape
+            ent = {"x": x.clone(), "logits": torch.empty(B, self.classes, H, W, dtype=torch.float32, device=x.device) if want_logits else None,
+                   "preds": None if preds is None else torch.empty_like(preds), "prob": None if prob is None else torch.empty_like(prob)}
+            g = torch.cuda.CUDAGraph()
+            l = L.lib()
+            with torch.cuda.graph(g):
+                L.check(l.flair_unet_reuse_constants(h, 1), "flair_unet_reuse_constants")
+                if preds is not None:
+                    L.check(l.flair_unet_want_preds(h, L.ptr(ent["preds"]), L.ptr(ent["prob"])), "flair_unet_want_preds")
+                L.check(l.flair_unet_forward(h, L.ptr(self._flat_p), L.ptr(self._flat_b), L.ptr(ent["x"]), L.ptr(ent["logits"]), B, H, W, 0,
+                                             L.ptr(ws), ws.numel(), L.stream()), "flair_unet_forward")
+            ent["graph"] = g
+            self._eval_graphs[gkey] = ent
+        ent["x"].copy_(x)       # (capture records, it does not run: the first use replays too)
+        ent["graph"].replay()
+        if preds is not None:
+            preds.copy_(ent["preds"])
+            if prob is not None:
+                prob.copy_(ent["prob"])
+        return None if ent["logits"] is None else ent["logits"].clone()
+
     @_on_model_device
-    def _c_forward(self, x, training, want_logits=True):
+    def _c_forward(self, x, training, want_logits=True, preds=None, prob=None):
         """want_logits=False (fused trainer): the head's output stays in the workspace as NHWC rows of the compute dtype
-        (flair_unet_logits_nhwc) and no fp32 NCHW tensor is produced; returns None."""
+        (flair_unet_logits_nhwc) and no fp32 NCHW tensor is produced; returns None.  preds / prob (eval mode, no logits): uint8
+        argmax and its fp32 probability from the head convolution's epilogue (flair_unet_want_preds)."""
         x = self._prep(x)
         B, _, H, W = x.shape
         ws = self._workspace(B, H, W, training)
-        logits = torch.empty(B, self.classes, H, W, dtype=torch.float32, device=x.device) if want_logits else None
         h = self._hh(training)
+        if not training:
+            ver = sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
+            key = (ver, self._flat_p._version, self._flat_b._version, self.__dict__.get("_native_writes", 0), B, H, W, ws.data_ptr())
+            graphs = self.__dict__.setdefault("_eval_graphs", {})
+            if self.__dict__.get("_eval_key") != key:
+                graphs.clear()
+                self._eval_hits = {}
+            elif (os.environ.get("FLAIR_EVAL_GRAPH", "1") != "0" and B * H * W <= self._GRAPH_MAX_PIXELS
+                  and not torch.cuda.is_current_stream_capturing()):
+                gkey = (want_logits, preds is not None, prob is not None)
+                hits = self.__dict__.setdefault("_eval_hits", {})
+                hits[gkey] = hits.get(gkey, 0) + 1
+                if gkey in graphs or hits[gkey] >= 2:   # (the first repeat ran eagerly with reuse: every kernel's one-time set-up is done)
+                    return self._eval_graph(gkey, x, want_logits, preds, prob, ws, h)
+        logits = torch.empty(B, self.classes, H, W, dtype=torch.float32, device=x.device) if want_logits else None
+        if preds is not None:
+            L.check(L.lib().flair_unet_want_preds(h, L.ptr(preds), L.ptr(prob)), "flair_unet_want_preds")
         if not training:
             # constant weights between two eval forwards (predict / zone_detect loops): skip the weight pack and the
             # BatchNorm-coefficient launches.  torch bumps a tensor's _version on every in-place write (optimizers,
@@ -623,8 +669,7 @@ class Unet(nn.Module):
         B, _, H, W = x.shape
         preds = torch.empty(B, H, W, dtype=torch.uint8, device=x.device)
         prob = torch.empty(B, H, W, dtype=torch.float32, device=x.device) if want_prob else None
-        L.check(L.lib().flair_unet_want_preds(self._hh(False), L.ptr(preds), L.ptr(prob)), "flair_unet_want_preds")
-        self._c_forward(x, training=False, want_logits=False)
+        self._c_forward(x, training=False, want_logits=False, preds=preds, prob=prob)
         return (preds, prob) if want_prob else preds
 
     def __del__(self):
@@ -636,7 +681,7 @@ class Unet(nn.Module):
         except Exception:
             pass
 
-    _NATIVE_STATE = ("_h", "_h_eval", "_eval_key", "_ws_need", "_split", "_ws", "_flat_p", "_flat_b", "_flat_n", "_grads", "_live_ws", "_split_ws")
+    _NATIVE_STATE = ("_h", "_h_eval", "_eval_key", "_eval_graphs", "_eval_hits", "_ws_need", "_split", "_ws", "_flat_p", "_flat_b", "_flat_n", "_grads", "_live_ws", "_split_ws")
 
     def __getstate__(self):
         d = dict(self.__dict__)

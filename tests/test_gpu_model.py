@@ -906,6 +906,37 @@ def test_fused_bn_backward_apply_is_bit_identical_to_the_separate_pass(dev, dtyp
         assert nz == 0, f"mode {mode}: {nz} of {g0.numel()} gradient elements differ, max |d| {float((g0 - g1).abs().max()):.3e}"
 
 
+def test_small_eval_forwards_replay_a_hip_graph_with_identical_results(dev):
+    """Launch-bound eval forwards (predict_step at the reference's batch size 1, data_module.py:100) are captured into a HIP
+    graph on their third identical call and replayed: same bits as the eager call for logits, argmax and probability, fresh
+    inputs honoured, and any weight change drops the graph."""
+    import flair_amd
+    _, hip = _pair(5, 13, 19, dev)
+    hip.eval()
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(1, 5, 128, 128, generator=g).to(dev) for _ in range(5)]
+    os.environ["FLAIR_EVAL_GRAPH"] = "0"
+    try:
+        with torch.no_grad():
+            want = [(hip(x).clone(), *[t.clone() for t in hip.predict_classes(x, want_prob=True)]) for x in xs]
+    finally:
+        os.environ.pop("FLAIR_EVAL_GRAPH")
+    hip._eval_key = None
+    with torch.no_grad():
+        for rep in range(2):
+            for x, (lg, pr, pb) in zip(xs, want):
+                assert torch.equal(hip(x), lg)
+                p, q = hip.predict_classes(x, want_prob=True)
+                assert torch.equal(p, pr) and torch.equal(q, pb)
+        assert len(hip._eval_graphs) == 2                      # logits, and preds + probability
+        next(iter(hip.parameters())).mul_(1.25)                # a torch in-place write: version counter moves
+        a = hip(xs[0])
+        assert len(hip._eval_graphs) == 0 and not torch.equal(a, want[0][0])
+        m2 = flair_amd.create_model("unet", "resnet34", encoder_weights=None, in_channels=5, classes=13, compute_dtype="f32")
+        m2.load_state_dict(hip.state_dict())
+        assert torch.equal(a, m2.to(dev).eval()(xs[0]))
+
+
 @pytest.mark.parametrize("dtype,classes", [("f32", 13), ("bf16", 13), ("bf16", 19), ("f32", 19)])
 def test_predict_argmax_from_the_head_epilogue_equals_argmax_of_the_logits(dev, dtype, classes):
     """SegTrainer.predict takes the argmax out of the head convolution's epilogue (flair_unet_want_preds).  It must equal the
