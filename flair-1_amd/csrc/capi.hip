@@ -414,6 +414,9 @@ int64_t flair_segformer_workspace_bytes(flair_segformer_t* h, int B, int H, int 
   if (!h || B < 1 || !h->net.shape_ok(H, W)) return -1;
   return (int64_t)h->net.workspace_bytes(B, H, W);
 }
+void flair_segformer_weights_changed(flair_segformer_t* h) {
+  if (h) h->net.weights_changed();
+}
 int flair_segformer_forward(flair_segformer_t* h, const float* params, const float* x_nchw, float* logits_quarter_nchw,
                             float* logits_full_nchw, int B, int H, int W, void* ws, size_t wsb, void* stream) {
   if (!h) return -1;

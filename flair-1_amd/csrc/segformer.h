@@ -39,6 +39,9 @@ class SegFormer {
   // align_corners = False) to the tile size.  Either may be null, not both.
   int forward(const float* params, const float* x_nchw, float* logits_quarter, float* logits_full, int B, int H, int W, void* ws,
               size_t ws_bytes, hipStream_t s);
+  // The packed weights at the front of the workspace are reused while `params` and `ws` stay the same pointers; call this after
+  // changing the parameter buffer's contents in place.
+  void weights_changed() { cache_ok_ = false; }
 
  private:
   std::vector<SfLin> lins;
@@ -52,6 +55,10 @@ class SegFormer {
   int err_ = 0;
   hipStream_t s_ = nullptr;
   const float* params_ = nullptr;
+  bool cache_ok_ = false;
+  const float* cache_params_ = nullptr;
+  const void* cache_ws_ = nullptr;
+  int cache_head_ = -1;
   long add_tensor(const std::string& name, int ndim, long d0, long d1, long d2, long d3, int kind);
   int add_lin(const std::string& name, int cin, int cout, int k, int stride, int pad, bool bias);
   int add_ln(const std::string& name, int C);

@@ -14,6 +14,12 @@ int sf_fuse_bias(const float* wf, int D, const float* b3, const float* b2, const
                  const float* shift, float* shift2, hipStream_t s);
 int sf_upsample_sum_bn_relu(int dtype, const void* g0, const void* g1, const void* g2, const void* g3, const float* scale, const float* shift2,
                             void* z, int B, int H, int W, int D, hipStream_t s);
+// the whole decode head after the per-stage products in one kernel (bf16; see segformer_ops.hip): f0 [B][H][W][64], w0 [D][64],
+// g1..g3 [B][H >> i][W >> i][D], wint = the 128 x 96 interpolation matrix (sf_head_wint), wc [32][D] (rows >= labels zero), out fp32 NCHW
+bool sf_head_fused_ok(int dtype, int H, int W, int C0, int D, int labels);
+int sf_head_wint(void* wint, hipStream_t s);
+int sf_head_fused(const void* f0, const void* w0, const void* g1, const void* g2, const void* g3, const void* wint, const float* scale,
+                  const float* shift2, const void* wc, const float* bc, float* out, int B, int H, int W, int D, int labels, hipStream_t s);
 // q [B][N][hidden], k / v [B][Nk][hidden] token-major, heads of 64 channels; out like q
 int sf_attention(int dtype, const void* q, const void* k, const void* v, void* out, int B, int N, int Nk, int hidden, hipStream_t s);
 }  // namespace flair

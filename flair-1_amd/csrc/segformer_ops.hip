@@ -6,7 +6,10 @@
 // Activations are token-major [B * H * W][C] = NHWC, T = float (parity mode, exact-fp32 MFMA) or bf16.
 #include "segformer_ops.h"
 
+#include <type_traits>
+
 #include "prof.h"
+#include "tune.h"
 
 namespace flair {
 namespace {
@@ -66,45 +69,117 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 
 // ------------------------------------------------------------------------------------------- depth-wise 3x3 + bias + GELU
 // SegformerMixMLP: dwconv(fc1(x)) then the exact (erf) GELU.  A thread keeps ONE 16-byte channel chunk for the whole launch —
-// its 9 x CH weights and CH biases live in registers — and walks pixels; neighbouring threads hold neighbouring chunks of the
-// same pixel, so every load and store of a wave is one contiguous run.  (First version: one (pixel, chunk) item per thread
-// with its 72 weights re-read at a 36-byte stride per item: 0.24 TB/s, half of the SegFormer forward.)
+// its 9 x CH weights and CH biases live in registers — and walks a segment of L pixels along an image row with the 3 x 3 window
+// of unpacked inputs in registers: three new chunks (the next column) per output instead of nine.  Neighbouring threads hold
+// neighbouring chunks of the same pixel, so every load and store of a wave is a contiguous run.  (History: one (pixel, chunk)
+// item per thread with its 72 weights re-read per item 0.24 TB/s; register-resident weights, nine loads and unpacks per output
+// 1.9 TB/s — ~430 vector instructions per 16 bytes of output, half of them unpacking and the library's branchy erff.)
+// The accumulation order (bias, then taps row-major) is the same in every version.
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict__ x, const float* __restrict__ w /* [C][3][3] */,
-                                                             const float* __restrict__ bias, T* __restrict__ y, int B, int H, int W, int C,
-                                                             int cg /* chunks per workgroup: min(C / CH, 256) */) {
-  constexpr int CH = Elem<T>::CH;
-  const int c = blockIdx.y * cg + threadIdx.x % cg;     // this thread's chunk
-  const int pl = threadIdx.x / cg, npl = 256 / cg;      // pixel lane of the workgroup
-  float wr[9][CH], bs[CH];
-#pragma unroll
-  for (int e = 0; e < CH; ++e) {
-    bs[e] = bias[c * CH + e];
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) wr[tp][e] = w[(c * CH + e) * 9 + tp];
+__device__ __forceinline__ float gelu_erf(float v) {
+  if constexpr (sizeof(T) == 4) {
+    return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));   // parity mode: the library's erf
+  } else {
+    // bf16 outputs (2^-9 relative): Phi(-|v|) = erfc(|v| / sqrt 2) / 2 by Abramowitz-Stegun 7.1.26 (|error| < 1e-7), branch-free
+    const float a = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.f));
+    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float h = p * t * __builtin_amdgcn_exp2f(a * a * -1.4426950408889634f);
+    return v * (v < 0.f ? h : 1.f - h);
   }
-  const long P = (long)B * H * W;
-  for (long p = (long)blockIdx.x * npl + pl; p < P; p += (long)gridDim.x * npl) {
-    const int px = (int)(p % W), py = (int)((p / W) % H);
-    const T* base = x + p * C + (long)c * CH;
-    float acc[CH];
+}
+
+// E = 4 channels per thread in both modes (16 bytes of fp32, 8 bytes of bf16): 36 + 36 registers of weights and window, so
+// four waves per SIMD are resident (E = 8 in bf16: 190 registers, two waves, 2.6 TB/s).  W % L == 0.
+template <typename T, int L>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void dwconv3x3_gelu_kernel(const T* x, const float* __restrict__ w /* [C][3][3] */,
+                                                             const float* __restrict__ bias, T* y, int B, int H, int W, int C,
+                                                             int cg /* 4-channel groups per workgroup: a power of two <= 256 */) {
+  constexpr int E = 4;
+  typedef typename std::conditional<sizeof(T) == 4, uint4, uint2>::type V;
+  const int c = blockIdx.y * cg + threadIdx.x % cg;     // this thread's channel group
+  const int pl = threadIdx.x / cg, npl = 256 / cg;      // pixel lane of the workgroup
+  float wr[9][E], bs[E];
 #pragma unroll
-    for (int e = 0; e < CH; ++e) acc[e] = bs[e];
+  for (int e = 0; e < E; ++e) {
+    bs[e] = bias[c * E + e];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const bool yok = (unsigned)(py + r - 1) < (unsigned)H;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const bool ok = yok && (unsigned)(px + q - 1) < (unsigned)W;
-        float f[CH];
-        chunk_to_f<T>(*reinterpret_cast<const uint4*>(ok ? base + ((long)(r - 1) * W + (q - 1)) * C : base), f);
-#pragma unroll
-        for (int e = 0; e < CH; ++e) acc[e] = fmaf(ok ? f[e] : 0.f, wr[r * 3 + q][e], acc[e]);
-      }
+    for (int tp = 0; tp < 9; ++tp) wr[tp][e] = w[(c * E + e) * 9 + tp];
+  }
+  auto unpack = [](const V& v, float* f) {
+    if constexpr (sizeof(T) == 4) {
+      f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    } else {
+      f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+      f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
     }
+  };
+  const int nseg = W / L;
+  const int items = B * H * nseg;                       // (image row, segment)
+  for (int it = blockIdx.x * npl + pl; it < items; it += gridDim.x * npl) {
+    const int seg = it % nseg, row = it / nseg, py = row % H;
+    const int xs = seg * L;
+    const T* rp = x + ((long)row * W) * C + (long)c * E;
+    T* yp = y + ((long)row * W) * C + (long)c * E;
+    const bool up = py > 0, dn = py < H - 1;
+    // rows outside the image: read the centre row instead (a valid address) and zero the values
+    const T* rows[3] = {up ? rp - (long)W * C : rp, rp, dn ? rp + (long)W * C : rp};
+    float win[3][3][E];                                 // [column slot][row][element]
+    V raw[3];                                           // the next column, in flight during one step's arithmetic
+    auto issue_col = [&](int xx, bool edge) {           // edge: this column may lie outside the image (compile-time per call site)
+      const int xo = ((!edge || (unsigned)xx < (unsigned)W) ? xx : 0) * C;
 #pragma unroll
-    for (int e = 0; e < CH; ++e) acc[e] = 0.5f * acc[e] * (1.f + erff(acc[e] * 0.70710678118654752f));
-    *reinterpret_cast<uint4*>(y + p * C + (long)c * CH) = f_to_chunk<T>(acc);
+      for (int r = 0; r < 3; ++r) raw[r] = *reinterpret_cast<const V*>(rows[r] + xo);
+    };
+    auto take_col = [&](int slot, int xx, bool edge) {
+      const bool xok = !edge || (unsigned)xx < (unsigned)W;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const bool ok = xok && (r == 0 ? up : r == 2 ? dn : true);
+        V v = raw[r];
+        if (r != 1 || edge) {
+          v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u;
+          if constexpr (sizeof(T) == 4) { v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u; }
+        }
+        unpack(v, win[slot][r]);
+      }
+    };
+    issue_col(xs - 1, true);
+    take_col(0, xs - 1, true);
+    issue_col(xs, false);
+    take_col(1, xs, false);
+    issue_col(xs + 1, L == 1);
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const int xx = xs + i;
+      take_col((i + 2) % 3, xx + 1, i == L - 1);
+      if (i + 1 < L) issue_col(xx + 2, i + 1 == L - 1);
+      float acc[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = bs[e];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[e] = fmaf(win[(i + q) % 3][r][e], wr[r * 3 + q][e], acc[e]);
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = gelu_erf<T>(acc[e]);
+      V o;
+      if constexpr (sizeof(T) == 4) {
+        o = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
+      } else {
+        o.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
+        o.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+      }
+      *reinterpret_cast<V*>(yp + xx * C) = o;
+      // keep the unrolled steps apart (x and y are deliberately NOT __restrict__: with no-alias loads the straight-line bf16 body
+      // gets all 48 loads of a segment hoisted to its top — 250 registers, or 140 spilled at four waves per SIMD)
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
@@ -148,9 +223,38 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const T* __restrict_
   }
 }
 
-// fp32 NCHW [B][C][h][w] -> fp32 NCHW [B][C][H][W] (the logits, x4)
-__global__ __launch_bounds__(256) void bilinear_nchw_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int h, int w,
-                                                                int H, int W) {
+// fp32 NCHW [B][C][h][w] -> fp32 NCHW [B][C][H][W] (the logits, x4).  A workgroup owns RPB output rows of one plane and a thread
+// four consecutive outputs (one 16-byte store); all index arithmetic is 32-bit.  (First version: one output per thread from a
+// flat 64-bit index, two 64-bit divisions per element: 1.2 TB/s.)  W % 4 == 0, H % RPB == 0.
+template <int RPB>
+__global__ __launch_bounds__(256) void bilinear_nchw_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int H, int W) {
+  const int W4 = W >> 2;
+  const long row0 = (long)blockIdx.x * RPB;             // first output row of this workgroup, over all planes
+  const int pl = (int)(row0 / H), oy0 = (int)(row0 - (long)pl * H);
+  const float* p = x + (long)pl * h * w;
+  float* yo = y + row0 * W;
+  for (int it = threadIdx.x; it < RPB * W4; it += 256) {
+    const int r = it / W4, k = it - r * W4;
+    int y0, y1;
+    float ly;
+    bilinear_src(oy0 + r, h, H, y0, y1, ly);
+    const float* r0 = p + y0 * w;
+    const float* r1 = p + y1 * w;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int x0, x1;
+      float lx;
+      bilinear_src(4 * k + j, w, W, x0, x1, lx);
+      o[j] = (1.f - ly) * ((1.f - lx) * r0[x0] + lx * r0[x1]) + ly * ((1.f - lx) * r1[x0] + lx * r1[x1]);
+    }
+    *reinterpret_cast<float4*>(yo + (long)r * W + 4 * k) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// the same, any shape: one output per thread
+__global__ __launch_bounds__(256) void bilinear_nchw_f32_any_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int h, int w,
+                                                                    int H, int W) {
   const long total = planes * H * W;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int ox = (int)(i % W), oy = (int)((i / W) % H);
@@ -239,6 +343,177 @@ __global__ __launch_bounds__(256) void upsample_sum_bn_relu_kernel(const T* __re
     for (int e = 0; e < CH; ++e) acc[e] = fmaxf(fmaf(acc[e], scale[c * CH + e], shift2[c * CH + e]), 0.f);
     *reinterpret_cast<uint4*>(z + p * D + (long)c * CH) = f_to_chunk<T>(acc);
   }
+}
+
+// ----------------------------------------------------------------------------------------- decode head in ONE kernel (bf16)
+// The restructured head still moved 3.5 GB per 32 windows: g_0 = W_0 f_0 (768 channels at 1/4 resolution) written and re-read,
+// z written and re-read by the classifier.  Everything after the per-stage products is local to a pixel tile, so one workgroup
+// takes a 16 x 8 tile of the 1/4-resolution grid through all of it, 64 of the D channels at a time, entirely on the matrix pipe:
+//   acc[ch][px]  = sum_k   W_0[ch][k] f_0[px][k]                 (K = 64: the stage-0 product, never stored)
+//                + sum_src G[src][ch] Wint[px][src]              (K = 96: the bilinear x2 / x4 / x8 upsamples of g_1, g_2, g_3 AS A
+//                                                                 PRODUCT with a constant 128 x 96 interpolation matrix over the
+//                                                                 60 + 24 + 12 source pixels under the tile; its entries a b / 4^s
+//                                                                 with odd a, b < 2^(s+1) are exact in bf16, the accumulation is fp32)
+//   z            = relu(scale[ch] acc + shift2[ch])  -> bf16, in the accumulator registers
+//   logits[cls][px] += sum_ch Wc[cls][ch] z[ch][px]              (the accumulator tiles ARE the B operand of the classifier product:
+//                                                                 cdna_hip_programming.md, 'An accumulator tile as the next MFMA's
+//                                                                 operand' — the k order inside a step is permuted, Wc is read with
+//                                                                 the same permutation)
+// Source pixels outside the image are the clamped ones (replicate), which is exactly align_corners = False's edge rule: the
+// two taps of a clamped coordinate coincide and their weights sum to one.  G chunks go global -> registers -> LDS one chunk
+// ahead and come back as A fragments through the transposing read (rows = source pixels, columns = channels).
+// HBM traffic per 32 windows: f_0 67 MB + g_1..3 268 MB + logits 40 MB, against 3.5 GB.
+constexpr int HT_W = 16, HT_H = 8, HT_PX = HT_W * HT_H, HT_SRC = 96, HT_ROW = 144 /* bytes per source pixel in LDS: 64 bf16 + pad */;
+
+// source pixel s of the patch -> stage (1..3), row, column inside that stage's patch (6 x 10, 4 x 6, 3 x 4)
+__host__ __device__ inline void head_src(int s, int& st, int& sy, int& sx) {
+  if (s < 60) { st = 1; sy = s / 10; sx = s % 10; }
+  else if (s < 84) { st = 2; sy = (s - 60) / 6; sx = (s - 60) % 6; }
+  else { st = 3; sy = (s - 84) / 4; sx = (s - 84) % 4; }
+}
+
+// Wint[px][src]: product of the two 1-D weights of an (unclamped) align_corners = False resize by 2^st at tile-local output
+// coordinate o; the patch of a stage starts one source pixel before the tile's first
+__global__ __launch_bounds__(256) void head_wint_kernel(bf16_t* __restrict__ wint) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HT_PX * HT_SRC) return;
+  const int px = i / HT_SRC, s = i % HT_SRC, ox = px % HT_W, oy = px / HT_W;
+  int st, sy, sx;
+  head_src(s, st, sy, sx);
+  const float inv = 1.f / (float)(1 << st);
+  auto w1 = [&](int o, int idx) {
+    const float sc = ((float)o + 0.5f) * inv - 0.5f, fl = floorf(sc), l1 = sc - fl;
+    const int i0 = (int)fl + 1;
+    return idx == i0 ? 1.f - l1 : idx == i0 + 1 ? l1 : 0.f;
+  };
+  wint[i] = f32_to_bf16(w1(oy, sy) * w1(ox, sx));
+}
+
+__global__ __launch_bounds__(256) void head_fused_kernel(const bf16_t* __restrict__ f0, const bf16_t* __restrict__ w0, const bf16_t* __restrict__ g1,
+                                                         const bf16_t* __restrict__ g2, const bf16_t* __restrict__ g3,
+                                                         const bf16_t* __restrict__ wint, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift2, const bf16_t* __restrict__ wc /* [32][D] */,
+                                                         const float* __restrict__ bc, float* __restrict__ out, int B, int H, int W, int D,
+                                                         int labels) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][HT_SRC * HT_ROW];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
+  const int tiles_x = W / HT_W, tiles_y = H / HT_H;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  const int x0 = tx * HT_W, y0 = ty * HT_H;
+  // ---- constant B fragments of this wave's two pixel rows (N tiles): f_0 (K = 64) and the interpolation matrix (K = 96)
+  u32x4 bf0[2][2], bw[2][3];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int oy = 2 * wave + n;
+    const bf16_t* fp = f0 + (((long)b * H + y0 + oy) * W + x0 + lr) * 64 + 8 * g;
+    bf0[n][0] = *reinterpret_cast<const u32x4*>(fp);
+    bf0[n][1] = *reinterpret_cast<const u32x4*>(fp + 32);
+    const bf16_t* wp = wint + (oy * HT_W + lr) * HT_SRC + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) bw[n][ks] = *reinterpret_cast<const u32x4*>(wp + ks * 32);
+  }
+  // ---- staging of the source patch: 96 pixels x 8 chunks of 16 bytes = 3 items per thread, the same items for every channel chunk
+  const bf16_t* sp[3];
+  int so[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = t + 256 * k, src = i >> 3, part = i & 7;
+    int st, sy, sx;
+    head_src(src, st, sy, sx);
+    const int hs = H >> st, ws = W >> st;
+    int cy = (y0 >> st) - 1 + sy, cx = (x0 >> st) - 1 + sx;
+    cy = cy < 0 ? 0 : cy > hs - 1 ? hs - 1 : cy;
+    cx = cx < 0 ? 0 : cx > ws - 1 ? ws - 1 : cx;
+    const bf16_t* gs = st == 1 ? g1 : st == 2 ? g2 : g3;
+    sp[k] = gs + (((long)b * hs + cy) * ws + cx) * D + part * 8;
+    so[k] = src * HT_ROW + part * 16;
+  }
+  u32x4 stg[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) stg[k] = *reinterpret_cast<const u32x4*>(sp[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(smem[0] + so[k]) = stg[k];
+  __syncthreads();
+  f32x4_t la[2][2];
+#pragma unroll
+  for (int cm = 0; cm < 2; ++cm)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) la[cm][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  const int q = lr >> 2, p = lr & 3;
+  const int nchunks = D / 64;
+  for (int c = 0; c < nchunks; ++c) {
+    const unsigned char* buf = smem[c & 1];
+    if (c + 1 < nchunks) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) stg[k] = *reinterpret_cast<const u32x4*>(sp[k] + (c + 1) * 64);
+    }
+    unsigned zp[2][4][2];   // [pixel row][16-channel tile][packed pairs]: z in bf16
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int ch0 = c * 64 + mt * 16;
+      const bf16_t* wp = w0 + (long)(ch0 + lr) * 64 + 8 * g;
+      const u32x4 aw0 = *reinterpret_cast<const u32x4*>(wp), aw1 = *reinterpret_cast<const u32x4*>(wp + 32);
+      u32x4 ag[3];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const unsigned char* a = buf + (ks * 32 + 8 * g + q) * HT_ROW + mt * 32 + 8 * p;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * HT_ROW));
+        ag[ks].x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+        ag[ks].y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+        ag[ks].z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+        ag[ks].w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+      }
+      const float4 sc4 = *reinterpret_cast<const float4*>(scale + ch0 + 4 * g), sh4 = *reinterpret_cast<const float4*>(shift2 + ch0 + 4 * g);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw0), __builtin_bit_cast(bf16x8_t, bf0[n][0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aw1), __builtin_bit_cast(bf16x8_t, bf0[n][1]), acc, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ag[ks]), __builtin_bit_cast(bf16x8_t, bw[n][ks]), acc, 0, 0, 0);
+        const float z0 = fmaxf(fmaf(acc[0], sc4.x, sh4.x), 0.f), z1 = fmaxf(fmaf(acc[1], sc4.y, sh4.y), 0.f);
+        const float z2 = fmaxf(fmaf(acc[2], sc4.z, sh4.z), 0.f), z3 = fmaxf(fmaf(acc[3], sc4.w, sh4.w), 0.f);
+        zp[n][mt][0] = (unsigned)f32_to_bf16(z0) | ((unsigned)f32_to_bf16(z1) << 16);
+        zp[n][mt][1] = (unsigned)f32_to_bf16(z2) | ((unsigned)f32_to_bf16(z3) << 16);
+      }
+    }
+    // ---- classifier: K step s = channels 32 s .. 32 s + 31 of the chunk; slot (g, j < 4) <- tile 2 s row 4 g + j, (g, j >= 4) <- tile 2 s + 1
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int cm = 0; cm < 2; ++cm) {
+        const bf16_t* cp = wc + (long)(cm * 16 + lr) * D + c * 64 + 32 * s2 + 4 * g;
+        const uint2 lo = *reinterpret_cast<const uint2*>(cp), hi = *reinterpret_cast<const uint2*>(cp + 16);
+        const u32x4 af = u32x4{lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const u32x4 zf = u32x4{zp[n][2 * s2][0], zp[n][2 * s2][1], zp[n][2 * s2 + 1][0], zp[n][2 * s2 + 1][1]};
+          la[cm][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, zf), la[cm][n], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < nchunks) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(smem[(c + 1) & 1] + so[k]) = stg[k];
+    }
+    __syncthreads();
+  }
+  // ---- logits^T[cls = 16 cm + 4 g + i][pixel (row 2 wave + n, column lr)] -> fp32 NCHW
+#pragma unroll
+  for (int cm = 0; cm < 2; ++cm)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cls = cm * 16 + 4 * g + i;
+      if (cls < labels) {
+        const float bias = bc ? bc[cls] : 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          out[(((long)b * labels + cls) * H + y0 + 2 * wave + n) * W + x0 + lr] = la[cm][n][i] + bias;
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------ attention
@@ -459,22 +734,37 @@ int sf_layernorm(int dtype, const void* x, const float* gamma, const float* beta
   return dtype == DT_F32 ? layernorm_t<float>(x, gamma, beta, y, rows, C, eps, s) : layernorm_t<bf16_t>(x, gamma, beta, y, rows, C, eps, s);
 }
 
+template <int L>
+static void dwconv_launch(int dtype, dim3 grid, const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int cg,
+                          hipStream_t s) {
+  if (dtype == DT_F32) hipLaunchKernelGGL((dwconv3x3_gelu_kernel<float, L>), grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, H, W, C, cg);
+  else hipLaunchKernelGGL((dwconv3x3_gelu_kernel<bf16_t, L>), grid, dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, H, W, C, cg);
+}
+
 int sf_dwconv3x3_gelu(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, hipStream_t s) {
-  const int ch = dtype == DT_F32 ? 4 : 8;
-  if (C % ch) return -2;
-  const int nch = C / ch;
+  if (C % 4) return -2;
+  const int ng = C / 4;                                   // 4-channel groups, one per thread
   int cg = 1;
-  while (cg * 2 <= 256 && nch % (cg * 2) == 0) cg *= 2;   // chunks per workgroup: the largest power of two dividing both 256 and the
-                                                          // chunk count (4 x 320 channels = 160 bf16 chunks -> 32 per workgroup, 5 groups)
-  const long P = (long)B * H * W;
+  while (cg * 2 <= 256 && ng % (cg * 2) == 0) cg *= 2;    // groups per workgroup: the largest power of two dividing both 256 and
+                                                          // the group count (4 x 320 channels = 320 groups -> 64 per workgroup, 5 in y)
+  int L = W % 16 == 0 ? 16 : W % 8 == 0 ? 8 : W % 4 == 0 ? 4 : W % 2 == 0 ? 2 : 1;   // pixels per segment
+  const int lmax = tune("FLAIR_SF_DW_L", dtype == DT_F32 ? 16 : 4);   // (bf16: 16 and 8 spill at four waves per SIMD)
+  while (L > lmax && L > 1) L >>= 1;
+  const long items = (long)B * H * (W / L);
+  if (items > (1L << 30)) return -2;
   const int npl = 256 / cg;
-  long gx = (P + (long)npl * 16 - 1) / ((long)npl * 16);   // ~16 pixels per thread amortise its 9 x CH weight loads
-  if (gx > 4096) gx = 4096;
+  long gx = (items + npl - 1) / npl;
+  if (gx > 8192) gx = 8192;
   if (gx < 1) gx = 1;
-  dim3 grid((unsigned)gx, nch / cg);
+  dim3 grid((unsigned)gx, ng / cg);
   ProfScope ps("sf_dwconv_gelu", 18.0 * B * H * W * C, 2.0 * B * H * W * C * dtype_size(dtype), s);
-  if (dtype == DT_F32) hipLaunchKernelGGL(dwconv3x3_gelu_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, B, H, W, C, cg);
-  else hipLaunchKernelGGL(dwconv3x3_gelu_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, B, H, W, C, cg);
+  switch (L) {
+    case 16: dwconv_launch<16>(dtype, grid, x, w, bias, y, B, H, W, C, cg, s); break;
+    case 8: dwconv_launch<8>(dtype, grid, x, w, bias, y, B, H, W, C, cg, s); break;
+    case 4: dwconv_launch<4>(dtype, grid, x, w, bias, y, B, H, W, C, cg, s); break;
+    case 2: dwconv_launch<2>(dtype, grid, x, w, bias, y, B, H, W, C, cg, s); break;
+    default: dwconv_launch<1>(dtype, grid, x, w, bias, y, B, H, W, C, cg, s); break;
+  }
   FLAIR_CHECK_LAUNCH();
   return 0;
 }
@@ -493,7 +783,12 @@ int sf_bilinear_nhwc(int dtype, const void* x, void* y, int B, int h, int w, int
 int sf_bilinear_nchw_f32(const float* x, float* y, long planes, int h, int w, int H, int W, hipStream_t s) {
   const long total = planes * H * W;
   ProfScope ps("sf_bilinear_logits", 0.0, 4.0 * (planes * H * W + planes * h * w), s);
-  hipLaunchKernelGGL(bilinear_nchw_f32_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, planes, h, w, H, W);
+  constexpr int RPB = 8;
+  if (W % 4 == 0 && H % RPB == 0 && planes * H / RPB < (1L << 31)) {
+    hipLaunchKernelGGL(bilinear_nchw_f32_kernel<RPB>, dim3((unsigned)(planes * H / RPB)), dim3(256), 0, s, x, y, h, w, H, W);
+  } else {
+    hipLaunchKernelGGL(bilinear_nchw_f32_any_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, planes, h, w, H, W);
+  }
   FLAIR_CHECK_LAUNCH();
   return 0;
 }
@@ -527,6 +822,29 @@ int sf_upsample_sum_bn_relu(int dtype, const void* g0, const void* g1, const voi
   else
     hipLaunchKernelGGL(upsample_sum_bn_relu_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)g0, (const bf16_t*)g1,
                        (const bf16_t*)g2, (const bf16_t*)g3, scale, shift2, (bf16_t*)z, B, H, W, D);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int sf_head_wint(void* wint, hipStream_t s) {
+  hipLaunchKernelGGL(head_wint_kernel, dim3((HT_PX * HT_SRC + 255) / 256), dim3(256), 0, s, (bf16_t*)wint);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+bool sf_head_fused_ok(int dtype, int H, int W, int C0, int D, int labels) {
+  return dtype == DT_BF16 && C0 == 64 && D % 64 == 0 && labels <= 32 && H % HT_H == 0 && W % HT_W == 0 && H >= 8 && W >= 16;
+}
+
+int sf_head_fused(const void* f0, const void* w0, const void* g1, const void* g2, const void* g3, const void* wint, const float* scale,
+                  const float* shift2, const void* wc, const float* bc, float* out, int B, int H, int W, int D, int labels, hipStream_t s) {
+  if (!sf_head_fused_ok(DT_BF16, H, W, 64, D, labels)) return -2;
+  const long tiles = (long)B * (H / HT_H) * (W / HT_W);
+  if (tiles > (1L << 30)) return -2;
+  ProfScope ps("sf_head_fused", 2.0 * B * H * W * D * (64.0 + HT_SRC + 32.0),
+               2.0 * B * H * W * 64 + 2.0 * B * H * W * D * (1.0 / 4 + 1.0 / 16 + 1.0 / 64) + 4.0 * B * H * W * labels, s);
+  hipLaunchKernelGGL(head_fused_kernel, dim3((unsigned)tiles), dim3(256), 0, s, (const bf16_t*)f0, (const bf16_t*)w0, (const bf16_t*)g1,
+                     (const bf16_t*)g2, (const bf16_t*)g3, (const bf16_t*)wint, scale, shift2, (const bf16_t*)wc, bc, out, B, H, W, D, labels);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }

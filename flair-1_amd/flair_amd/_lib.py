@@ -81,6 +81,7 @@ PROTOTYPES = {
     "flair_segformer_num_tensors": (i32, [vp]),
     "flair_segformer_tensor_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]),
     "flair_segformer_workspace_bytes": (i64, [vp, i32, i32, i32]),
+    "flair_segformer_weights_changed": (None, [vp]),
     "flair_segformer_forward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "flair_tune_set": (i32, [C.c_char_p, i32]),
     "flair_debug_buffer": (i32, [vp]),

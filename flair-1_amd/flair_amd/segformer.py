@@ -79,6 +79,7 @@ class SegformerForSemanticSegmentation(nn.Module):
             self._attach(name, t, kind)
         self._attach("decode_head.batch_norm.num_batches_tracked", torch.zeros((), dtype=torch.int64), 1)
         self._flat = None
+        self._version = -1
         self._ws = None
         self.eval()
 
@@ -125,13 +126,18 @@ class SegformerForSemanticSegmentation(nn.Module):
         ok = self._flat is not None and self._flat.device == dev
         if ok:
             base = self._flat.data_ptr()
+            version = 0
             for name, (shape, off, _) in self._layout.items():
                 mod, leaf = self._tensor(name)
                 t = getattr(mod, leaf)
                 if t.data_ptr() != base + 4 * off or t.dtype != torch.float32:
                     ok = False
                     break
+                version += t._version
         if ok:
+            if version != self._version:      # an in-place update (load_state_dict, copy_, ...) since the last forward:
+                self.weights_changed()        # the library re-packs its cached weight layouts
+                self._version = version
             return self._flat
         flat = torch.zeros(self._n, dtype=torch.float32, device=dev)
         with torch.no_grad():
@@ -142,7 +148,14 @@ class SegformerForSemanticSegmentation(nn.Module):
                 view.copy_(t.detach().to(device=dev, dtype=torch.float32))
                 t.data = view
         self._flat = flat
+        self._version = sum(getattr(*self._tensor(name))._version for name in self._layout)
+        self.weights_changed()
         return flat
+
+    def weights_changed(self):
+        """The library keeps packed copies of the weights between forwards; in-place updates through the module's parameters are
+        noticed (tensor version counters), updates through ``.data`` or raw pointers are not — call this after such an update."""
+        L.lib().flair_segformer_weights_changed(self._h)
 
     # ---- native forward
     def _run(self, x, want_quarter, want_full):

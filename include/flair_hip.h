@@ -242,6 +242,11 @@ int flair_segformer_num_tensors(const flair_segformer_t* h);
 int flair_segformer_tensor_info(const flair_segformer_t* h, int i, char* name, int name_cap, int64_t shape[4], int* ndim,
                                 int64_t* offset, int* kind);
 int64_t flair_segformer_workspace_bytes(flair_segformer_t* h, int B, int H, int W);
+/* The forward keeps what depends on the weights alone (packed GEMM operands, folded BatchNorm, the decode head's
+ * pre-multiplied matrices) at the front of the workspace and reuses it while `params` and `workspace` are the
+ * same pointers as in the previous call.  Call this after changing the parameter buffer's CONTENTS in place
+ * (transformers has no counterpart: its modules read their weights on every call). */
+void flair_segformer_weights_changed(flair_segformer_t* h);
 /* logits_quarter_nchw: fp32 (B, labels, H/4, W/4) = the library's `.logits`; logits_full_nchw: the same after
  * nn.functional.interpolate(size=(H, W), mode="bilinear", align_corners=False), what softmax / margin crop /
  * convert (compare.py:35, 69-82) need at tile resolution.  Either may be NULL, not both. */

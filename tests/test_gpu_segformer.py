@@ -69,10 +69,38 @@ def test_restructured_decode_head_equals_the_librarys_order(dev):
         L.check(L.lib().flair_tune_set(b"FLAIR_SF_HEAD", 0))
         a = hip(x.to(dev)).logits.cpu()
     finally:
-        L.lib().flair_tune_set(b"FLAIR_SF_HEAD", 1)
+        L.lib().flair_tune_set(b"FLAIR_SF_HEAD", 2)
     b = hip(x.to(dev)).logits.cpu()
     assert float((a - b).abs().max()) < 2e-5
     assert float((a - want).abs().max()) < 5e-5 and float((b - want).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 128), (1, 128, 128), (1, 512, 512)])
+def test_fused_decode_head_kernel_matches_the_separate_passes_bf16(dev, shape):
+    """bf16 runs everything after the per-stage products of the decode head in one kernel (head_fused_kernel: stage-0 product,
+    the three bilinear upsamples as a product with a constant interpolation matrix, folded BatchNorm + ReLU, classifier; 16 x 8
+    pixel tiles).  FLAIR_SF_HEAD=1 runs the separate passes (product -> upsample-sum -> classifier, each rounding its output to
+    bf16).  The two differ by those roundings only: measured max 4e-3 / rms 6e-4 of the logit scale; edge tiles (clamped source
+    pixels), a non-square grid and the 2 x 2-tile minimum are covered by the shapes.  Both sit on the fp32 oracle by the bf16 rule."""
+    from flair_amd import _lib as L
+    from oracle import parity
+    from oracle import segformer as osf
+    ref, hip = _pair(dev, "bf16")
+    x = torch.randn(*[shape[0], 5, shape[1], shape[2]], generator=torch.Generator().manual_seed(21))
+    fused = hip(x.to(dev)).logits.cpu()
+    try:
+        L.check(L.lib().flair_tune_set(b"FLAIR_SF_HEAD", 1))
+        sep = hip(x.to(dev)).logits.cpu()
+    finally:
+        L.lib().flair_tune_set(b"FLAIR_SF_HEAD", 2)
+    want = osf.logits(ref, x)[0]
+    scale = float(want.abs().max())
+    d = (fused - sep).abs()
+    parity.record({"test": f"segformer_fused_head_{shape[0]}x{shape[1]}x{shape[2]}", "logit_scale": scale, "max_abs": float(d.max()),
+                   "rms": float(d.pow(2).mean().sqrt()), "fused_vs_oracle_max": float((fused - want).abs().max()),
+                   "separate_vs_oracle_max": float((sep - want).abs().max())})
+    assert float(d.max()) < 1.5e-2 * scale and float(d.pow(2).mean().sqrt()) < 2e-3 * scale
+    assert float((fused - want).abs().max()) < 3e-2 * scale and float((fused - want).pow(2).mean().sqrt()) < 6e-3 * scale
 
 
 def test_bf16_mode_tracks_the_oracle(dev):
@@ -108,6 +136,30 @@ def test_contract(dev):
     with pytest.raises(NotImplementedError):
         flair_amd.FLAIR_ModelFactory({**cfg, "model_framework": {"model_provider": "HuggingFace",
                                                                  "HuggingFace": {"org_model": "openmmlab/upernet-swin-small"}}})
+
+
+def test_cached_weight_layouts_follow_the_parameters(dev):
+    """The library keeps packed weights / the decode head's pre-multiplied matrices between forwards
+    (flair_segformer_weights_changed): an in-place update of the parameters — load_state_dict, copy_ — must be seen by the next
+    forward, the same weights must give the same bits with a warm and a cold cache, and another batch size (another workspace)
+    must not read stale layouts."""
+    from oracle import segformer as osf
+    ref, hip = _pair(dev, seed=11)
+    x = torch.randn(2, 5, 128, 128, generator=torch.Generator().manual_seed(8))
+    cold = hip(x.to(dev)).logits.clone()
+    warm = hip(x.to(dev)).logits.clone()
+    assert torch.equal(cold, warm)
+    ref2 = osf.seeded_model(5, 19, seed=12)
+    hip.load_state_dict(ref2.state_dict(), strict=True)               # in place: same pointers, new contents
+    assert float((hip(x.to(dev)).logits.cpu() - osf.logits(ref2, x)[0]).abs().max()) < 5e-5
+    with torch.no_grad():
+        hip.decode_head.classifier.bias.add_(1.0)                     # a single tensor, in place
+    assert float((hip(x.to(dev)).logits.cpu() - (osf.logits(ref2, x)[0] + 1.0)).abs().max()) < 5e-5
+    big = torch.randn(4, 5, 256, 256, generator=torch.Generator().manual_seed(9))   # larger workspace -> new buffer
+    with torch.no_grad():
+        ref2.decode_head.classifier.bias.add_(1.0)
+    assert float((hip(big.to(dev)).logits.cpu() - osf.logits(ref2, big)[0]).abs().max()) < 5e-5
+    assert float((hip(x.to(dev)).logits.cpu() - osf.logits(ref2, x)[0]).abs().max()) < 5e-5
 
 
 def test_zone_detector_with_segformer_matches_sequential_replay(dev):
