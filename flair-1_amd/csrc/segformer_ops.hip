@@ -389,32 +389,25 @@ __global__ __launch_bounds__(256) void head_wint_kernel(bf16_t* __restrict__ win
   wint[i] = f32_to_bf16(w1(oy, sy) * w1(ox, sx));
 }
 
+// LDS image of one channel chunk: the source patch [96][64 + pad], W_0 rows [64 ch][64 k + pad], classifier rows [32 cls][64 ch + pad],
+// scale / shift2 [2][64] fp32 — everything the chunk's MFMAs read, staged one chunk ahead (global -> registers -> LDS).  (First
+// version: the weight fragments straight from global memory inside the chunk loop, 481 us: every chunk waited for L2 round trips.)
+constexpr int HT_W0 = HT_SRC * HT_ROW, HT_WC = HT_W0 + 64 * HT_ROW, HT_SS = HT_WC + 32 * HT_ROW, HT_BUF = HT_SS + 512;
+
 __global__ __launch_bounds__(256) void head_fused_kernel(const bf16_t* __restrict__ f0, const bf16_t* __restrict__ w0, const bf16_t* __restrict__ g1,
                                                          const bf16_t* __restrict__ g2, const bf16_t* __restrict__ g3,
                                                          const bf16_t* __restrict__ wint, const float* __restrict__ scale,
                                                          const float* __restrict__ shift2, const bf16_t* __restrict__ wc /* [32][D] */,
                                                          const float* __restrict__ bc, float* __restrict__ out, int B, int H, int W, int D,
                                                          int labels) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2][HT_SRC * HT_ROW];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][HT_BUF];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
   const int tiles_x = W / HT_W, tiles_y = H / HT_H;
   const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
   const int x0 = tx * HT_W, y0 = ty * HT_H;
-  // ---- constant B fragments of this wave's two pixel rows (N tiles): f_0 (K = 64) and the interpolation matrix (K = 96)
-  u32x4 bf0[2][2], bw[2][3];
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int oy = 2 * wave + n;
-    const bf16_t* fp = f0 + (((long)b * H + y0 + oy) * W + x0 + lr) * 64 + 8 * g;
-    bf0[n][0] = *reinterpret_cast<const u32x4*>(fp);
-    bf0[n][1] = *reinterpret_cast<const u32x4*>(fp + 32);
-    const bf16_t* wp = wint + (oy * HT_W + lr) * HT_SRC + 8 * g;
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) bw[n][ks] = *reinterpret_cast<const u32x4*>(wp + ks * 32);
-  }
-  // ---- staging of the source patch: 96 pixels x 8 chunks of 16 bytes = 3 items per thread, the same items for every channel chunk
-  const bf16_t* sp[3];
-  int so[3];
+  // ---- staging items of a chunk: patch 96 x 8 (3 per thread), W_0 64 x 8 (2), classifier 32 x 8 (1), scale / shift 32 (threads < 32)
+  const bf16_t* sp[6];
+  int so[6], sstep[6];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int i = t + 256 * k, src = i >> 3, part = i & 7;
@@ -427,12 +420,48 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const bf16_t* __restric
     const bf16_t* gs = st == 1 ? g1 : st == 2 ? g2 : g3;
     sp[k] = gs + (((long)b * hs + cy) * ws + cx) * D + part * 8;
     so[k] = src * HT_ROW + part * 16;
+    sstep[k] = 64;
   }
-  u32x4 stg[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) stg[k] = *reinterpret_cast<const u32x4*>(sp[k]);
+  for (int k = 0; k < 2; ++k) {
+    const int i = t + 256 * k, row = i >> 3, part = i & 7;
+    sp[3 + k] = w0 + (long)row * 64 + part * 8;
+    so[3 + k] = HT_W0 + row * HT_ROW + part * 16;
+    sstep[3 + k] = 64 * 64;
+  }
+  {
+    const int row = t >> 3, part = t & 7;
+    sp[5] = wc + (long)row * D + part * 8;
+    so[5] = HT_WC + row * HT_ROW + part * 16;
+    sstep[5] = 64;
+  }
+  const float* ssp = (t < 16 ? scale + 4 * t : shift2 + 4 * (t & 15));   // threads 0..15 scale, 16..31 shift2
+  u32x4 stg[6];
+  float4 sst = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto stage_load = [&](int c) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(smem[0] + so[k]) = stg[k];
+    for (int k = 0; k < 6; ++k) stg[k] = *reinterpret_cast<const u32x4*>(sp[k] + (long)c * sstep[k]);
+    if (t < 32) sst = *reinterpret_cast<const float4*>(ssp + c * 64);
+  };
+  auto stage_store = [&](unsigned char* buf) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) *reinterpret_cast<u32x4*>(buf + so[k]) = stg[k];
+    if (t < 32) *reinterpret_cast<float4*>(buf + HT_SS + t * 16) = sst;
+  };
+  stage_load(0);
+  // ---- constant B fragments of this wave's two pixel rows (N tiles): f_0 (K = 64) and the interpolation matrix (K = 96)
+  u32x4 bf0[2][2], bw[2][3];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int oy = 2 * wave + n;
+    const bf16_t* fp = f0 + (((long)b * H + y0 + oy) * W + x0 + lr) * 64 + 8 * g;
+    bf0[n][0] = *reinterpret_cast<const u32x4*>(fp);
+    bf0[n][1] = *reinterpret_cast<const u32x4*>(fp + 32);
+    const bf16_t* wp = wint + (oy * HT_W + lr) * HT_SRC + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) bw[n][ks] = *reinterpret_cast<const u32x4*>(wp + ks * 32);
+  }
+  stage_store(smem[0]);
   __syncthreads();
   f32x4_t la[2][2];
 #pragma unroll
@@ -444,16 +473,12 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const bf16_t* __restric
   const int nchunks = D / 64;
   for (int c = 0; c < nchunks; ++c) {
     const unsigned char* buf = smem[c & 1];
-    if (c + 1 < nchunks) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) stg[k] = *reinterpret_cast<const u32x4*>(sp[k] + (c + 1) * 64);
-    }
+    if (c + 1 < nchunks) stage_load(c + 1);
     unsigned zp[2][4][2];   // [pixel row][16-channel tile][packed pairs]: z in bf16
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const int ch0 = c * 64 + mt * 16;
-      const bf16_t* wp = w0 + (long)(ch0 + lr) * 64 + 8 * g;
-      const u32x4 aw0 = *reinterpret_cast<const u32x4*>(wp), aw1 = *reinterpret_cast<const u32x4*>(wp + 32);
+      const unsigned char* wr = buf + HT_W0 + (mt * 16 + lr) * HT_ROW + 16 * g;
+      const u32x4 aw0 = *reinterpret_cast<const u32x4*>(wr), aw1 = *reinterpret_cast<const u32x4*>(wr + 64);
       u32x4 ag[3];
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
@@ -465,7 +490,8 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const bf16_t* __restric
         ag[ks].z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
         ag[ks].w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
       }
-      const float4 sc4 = *reinterpret_cast<const float4*>(scale + ch0 + 4 * g), sh4 = *reinterpret_cast<const float4*>(shift2 + ch0 + 4 * g);
+      const float4 sc4 = *reinterpret_cast<const float4*>(buf + HT_SS + (mt * 16 + 4 * g) * 4);
+      const float4 sh4 = *reinterpret_cast<const float4*>(buf + HT_SS + 256 + (mt * 16 + 4 * g) * 4);
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -485,8 +511,8 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const bf16_t* __restric
     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
       for (int cm = 0; cm < 2; ++cm) {
-        const bf16_t* cp = wc + (long)(cm * 16 + lr) * D + c * 64 + 32 * s2 + 4 * g;
-        const uint2 lo = *reinterpret_cast<const uint2*>(cp), hi = *reinterpret_cast<const uint2*>(cp + 16);
+        const unsigned char* cp = buf + HT_WC + (cm * 16 + lr) * HT_ROW + (32 * s2 + 4 * g) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(cp), hi = *reinterpret_cast<const uint2*>(cp + 32);
         const u32x4 af = u32x4{lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -495,10 +521,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const bf16_t* __restric
         }
       }
     }
-    if (c + 1 < nchunks) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(smem[(c + 1) & 1] + so[k]) = stg[k];
-    }
+    if (c + 1 < nchunks) stage_store(smem[(c + 1) & 1]);
     __syncthreads();
   }
   // ---- logits^T[cls = 16 cm + 4 g + i][pixel (row 2 wave + n, column lr)] -> fp32 NCHW
