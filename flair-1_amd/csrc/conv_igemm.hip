@@ -11,6 +11,7 @@
 // plus per-row-block partial BatchNorm sums (deterministic: no atomics).
 #include "common.h"
 #include "prof.h"
+#include "tune.h"
 
 namespace flair {
 
@@ -389,7 +390,14 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
   if (a.out && (a.Cout % CH)) return -3;
   if (a.up0 && ((a.Hin | a.Win) & 1)) return -4;
   if (a.in_div != 1 && a.in_div != 2) return -5;
-  switch (pick_bn(a.Cout)) {
+  // few pixel rows, long K (the SegFormer sequence-reduction convolutions: 8 192 rows x K = 1 280 .. 4 096 at B = 32, 64 workgroups
+  // of 128 rows on 256 CUs): 32-row tiles, four times the workgroups
+  const long M = (long)a.N * a.Hout * a.Wout;
+  const int bn = pick_bn(a.Cout);
+  const bool small = !a.stats && !a.ncls && bn >= 64 && a.Kpad >= 8 * 8 * Elem<T>::CH && (long)cdiv(M, 128) * cdiv(a.Cout, bn) < 256 &&
+                     tune("FLAIR_IGEMM_BM32", 1);
+  if (small) return bn == 128 ? launch_cfg<T, 32, 128, 2, 2>(a, s) : launch_cfg<T, 32, 64, 2, 2>(a, s);
+  switch (bn) {
     case 128: return launch_cfg<T, 128, 128, 2, 2>(a, s);
     case 64: return launch_cfg<T, 128, 64, 4, 1>(a, s);
     case 32: return launch_cfg<T, 256, 32, 4, 1>(a, s);

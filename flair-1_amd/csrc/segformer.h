@@ -55,6 +55,8 @@ class SegFormer {
   int err_ = 0;
   hipStream_t s_ = nullptr;
   const float* params_ = nullptr;
+  std::vector<size_t> kv_w_;   // per block, in stage order: arena offset of the fused [k; v] packed weight, its concatenated bias
+  std::vector<float*> kv_b_;
   bool cache_ok_ = false;
   const float* cache_params_ = nullptr;
   const void* cache_ws_ = nullptr;

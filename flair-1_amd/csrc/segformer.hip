@@ -173,6 +173,37 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
       }
     }
   }
+  // key and value projections of a block as ONE product over [k_proj.weight; v_proj.weight] (2 h rows) with the concatenated bias:
+  // they read the same (reduced) sequence of 8 192 tokens at B = 32 — two 7-16 us launches of 64 workgroups each otherwise
+  kv_w_.clear(); kv_b_.clear();
+  {
+    PackTable tb;
+    tb.n = 0;
+    for (size_t si = 0; si < stages.size(); ++si)
+      for (const SfBlock& K : stages[si].blocks) {
+        const SfLin& Lk = lins[K.k];
+        const SfLin& Lv = lins[K.v];
+        const int h = Lk.cout, rows = conv_weight_rows_pad(2 * h);
+        const size_t off = top_;
+        alloc((size_t)rows * Lk.Kpad * es);
+        float* bias = (float*)alloc((size_t)2 * h * 4);
+        kv_w_.push_back(off); kv_b_.push_back(bias);
+        if (fresh || dry_) continue;
+        for (int half = 0; half < 2; ++half) {
+          const SfLin& L = half ? Lv : Lk;
+          PackDesc& d = tb.d[tb.n++];
+          memset(&d, 0, sizeof(d));
+          d.w_off = L.w_off; d.dst_off = off + (size_t)half * h * Lk.Kpad * es; d.Cout = h; d.Cin = L.cin; d.R = 1; d.S = 1;
+          d.Cin_p = L.cin_p; d.rows_pad = half ? rows - h : h; d.Kpad = Lk.Kpad; d.tf = 0;
+          if (!err_ && hipMemcpyAsync(bias + half * h, params_ + L.b_off, (size_t)h * 4, hipMemcpyDeviceToDevice, s_) != hipSuccess) err_ = -101;
+        }
+        if (tb.n + 2 > PackTable::MAX) {
+          SF_RUN(pack_weights_all(dtype, params_, base_, tb, s_));
+          tb.n = 0;
+        }
+      }
+    if (tb.n) SF_RUN(pack_weights_all(dtype, params_, base_, tb, s_));
+  }
   float* bn_scale = (float*)alloc((size_t)dec_hidden * 4);
   float* bn_shift = (float*)alloc((size_t)dec_hidden * 4);
   if (!fresh) SF_RUN(bn_eval_coeffs(dec_hidden, params_ + bn_g, params_ + bn_b, params_ + bn_rm, params_ + bn_rv, 1e-5f, bn_scale, bn_shift, s_));
@@ -237,6 +268,7 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
     feat[i] = alloc((size_t)B * fh[i] * fw[i] * hidden[i] * es);
   }
   // ---- encoder
+  size_t blk = 0;
   const void* sin = xin;
   int sH = H, sW = W;
   for (int i = 0; i < 4; ++i) {
@@ -254,8 +286,7 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
     const long ktok = (long)B * Hk * Wk;
     void* red = alloc((size_t)ktok * h * es);
     void* redn = alloc((size_t)ktok * h * es);
-    void* kb = alloc((size_t)ktok * h * es);
-    void* vb = alloc((size_t)ktok * h * es);
+    void* kvb = alloc((size_t)ktok * 2 * h * es);
     // overlapping patch embedding (strided convolution + bias), LayerNorm
     gemm(lins[S.patch], sin, B, sH, sW, ln, h, nullptr, nullptr, nullptr, 0, nullptr);
     layernorm(norms[S.patch_ln], ln, x, tokens);
@@ -268,9 +299,16 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
         layernorm(norms[K.sr_ln], red, redn, ktok);
         kv_in = redn;
       }
-      gemm(lins[K.k], kv_in, B, Hk, Wk, kb, h, nullptr, nullptr, nullptr, 0, nullptr);
-      gemm(lins[K.v], kv_in, B, Hk, Wk, vb, h, nullptr, nullptr, nullptr, 0, nullptr);
-      SF_RUN(sf_attention(dtype, qb, kb, vb, ctx, B, Hs * Ws, Hk * Wk, h, s_));
+      {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        const SfLin& Lk = lins[K.k];
+        a.src0 = kv_in; a.C0 = Lk.cin_p; a.N = B; a.Hin = Hk; a.Win = Wk; a.Hout = Hk; a.Wout = Wk; a.R = 1; a.S = 1; a.out_mul = 1; a.in_div = 1;
+        a.Cout = 2 * h; a.Kg = Lk.Kg; a.Kpad = Lk.Kpad; a.w = base_ + kv_w_[blk]; a.bias = kv_b_[blk]; a.out = kvb; a.out_ld = 2 * h;
+        SF_RUN(launch_conv(dtype, a, s_));
+      }
+      ++blk;
+      SF_RUN(sf_attention(dtype, qb, kvb, (const unsigned char*)kvb + (size_t)h * es, ctx, B, Hs * Ws, Hk * Wk, h, 2 * h, s_));
       gemm(lins[K.o], ctx, B, Hs, Ws, x, h, /*residual*/ x, nullptr, nullptr, 0, nullptr);   // x = o_proj(ctx) + x, element by element in place
       layernorm(norms[K.ln2], x, ln, tokens);
       gemm(lins[K.fc1], ln, B, Hs, Ws, f1, 4 * h, nullptr, nullptr, nullptr, 0, nullptr);

@@ -20,6 +20,7 @@ bool sf_head_fused_ok(int dtype, int H, int W, int C0, int D, int labels);
 int sf_head_wint(void* wint, hipStream_t s);
 int sf_head_fused(const void* f0, const void* w0, const void* g1, const void* g2, const void* g3, const void* wint, const float* scale,
                   const float* shift2, const void* wc, const float* bc, float* out, int B, int H, int W, int D, int labels, hipStream_t s);
-// q [B][N][hidden], k / v [B][Nk][hidden] token-major, heads of 64 channels; out like q
-int sf_attention(int dtype, const void* q, const void* k, const void* v, void* out, int B, int N, int Nk, int hidden, hipStream_t s);
+// q [B][N][hidden], k / v [B][Nk] rows of kv_ld elements (hidden of them used: k and v may interleave as the halves of one fused
+// projection), token-major, heads of 64 channels; out like q
+int sf_attention(int dtype, const void* q, const void* k, const void* v, void* out, int B, int N, int Nk, int hidden, int kv_ld, hipStream_t s);
 }  // namespace flair

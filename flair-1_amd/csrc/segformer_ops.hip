@@ -558,7 +558,7 @@ template <> struct AttCfg<float> {
 
 template <typename T, int NKT /* key tiles of 16 */>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                        T* __restrict__ out, int N, int Nk, int hidden, int qblocks) {
+                                                        T* __restrict__ out, int N, int Nk, int hidden, int qblocks, int kv_ld) {
   constexpr int CH = Elem<T>::CH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -568,30 +568,47 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
   unsigned char* ks = smem;
   unsigned char* vt = smem + (size_t)Nk * KROW;
   // ---- K rows and V^T into LDS
-  const T* kb = k + ((long)b * Nk) * hidden + head * 64;
-  const T* vb = v + ((long)b * Nk) * hidden + head * 64;
+  const T* kb = k + ((long)b * Nk) * kv_ld + head * 64;   // (kv_ld: k and v may be the two halves of one fused projection's rows)
+  const T* vb = v + ((long)b * Nk) * kv_ld + head * 64;
   constexpr int CPR = 64 / CH;   // 16-byte chunks per 64-channel row
   for (int i = t; i < Nk * CPR; i += 256) {
     const int key = i / CPR, c = i % CPR;
-    *reinterpret_cast<uint4*>(ks + key * KROW + c * 16) = *reinterpret_cast<const uint4*>(kb + (long)key * hidden + c * CH);
-    const uint4 vv = *reinterpret_cast<const uint4*>(vb + (long)key * hidden + c * CH);
+    *reinterpret_cast<uint4*>(ks + key * KROW + c * 16) = *reinterpret_cast<const uint4*>(kb + (long)key * kv_ld + c * CH);
+    const uint4 vv = *reinterpret_cast<const uint4*>(vb + (long)key * kv_ld + c * CH);
     const T* ve = reinterpret_cast<const T*>(&vv);
 #pragma unroll
     for (int e = 0; e < CH; ++e) *reinterpret_cast<T*>(vt + (c * CH + e) * VROW + key * (int)sizeof(T)) = ve[e];
   }
   __syncthreads();
   const float scale = 0.125f;   // 64 ** -0.5
+  // bf16: the query fragments of block qb + 1 are loaded while block qb is computed (a block is ~1.5 us of arithmetic behind
+  // a ~2 us HBM round trip, and only two workgroups fit a CU)
+  auto q_ptr = [&](int qb) {
+    const int q0 = (blockIdx.x * qblocks + qb) * 64 + wave * 16;
+    const int qi = q0 + lr < N ? q0 + lr : N - 1;   // ragged tail: clamp, masked at the store
+    return q + ((long)b * N + qi) * hidden + head * 64;
+  };
+  u32x4 qn0 = u32x4{0u, 0u, 0u, 0u}, qn1 = qn0;
+  if constexpr (sizeof(T) == 2) {
+    const T* qp0 = q_ptr(0);
+    qn0 = *reinterpret_cast<const u32x4*>(qp0 + 8 * g);
+    qn1 = *reinterpret_cast<const u32x4*>(qp0 + 32 + 8 * g);
+  }
   for (int qb = 0; qb < qblocks; ++qb) {
     const int q0 = (blockIdx.x * qblocks + qb) * 64 + wave * 16;
     if (q0 >= N) break;   // wave-uniform
-    const int qi = q0 + lr < N ? q0 + lr : N - 1;   // ragged tail: clamp, masked at the store
-    const T* qp = q + ((long)b * N + qi) * hidden + head * 64;
+    const T* qp = q_ptr(qb);
     f32x4_t acc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) acc[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if constexpr (sizeof(T) == 2) {
       // B = Q^T: lane holds Q[query lr][dims 8g .. 8g+7] (+32 for the second K step)
-      const u32x4 qf0 = *reinterpret_cast<const u32x4*>(qp + 8 * g), qf1 = *reinterpret_cast<const u32x4*>(qp + 32 + 8 * g);
+      const u32x4 qf0 = qn0, qf1 = qn1;
+      if (qb + 1 < qblocks) {   // (rows past N clamp to the last query)
+        const T* qpn = q_ptr(qb + 1);
+        qn0 = *reinterpret_cast<const u32x4*>(qpn + 8 * g);
+        qn1 = *reinterpret_cast<const u32x4*>(qpn + 32 + 8 * g);
+      }
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
         if (kt * 16 < Nk) {
@@ -726,7 +743,7 @@ int layernorm_t(const void* x, const float* gamma, const float* beta, void* y, l
 }
 
 template <typename T, int NKT>
-int attention_launch(const void* q, const void* k, const void* v, void* out, int B, int N, int Nk, int hidden, hipStream_t s) {
+int attention_launch(const void* q, const void* k, const void* v, void* out, int B, int N, int Nk, int hidden, int kv_ld, hipStream_t s) {
   auto kern = attention_kernel<T, NKT>;
   const int smem = Nk * AttCfg<T>::KROW + 64 * AttCfg<T>::vrow(Nk);
   static bool attr_set = false;
@@ -743,7 +760,7 @@ int attention_launch(const void* q, const void* k, const void* v, void* out, int
   dim3 grid((N + 64 * qblocks - 1) / (64 * qblocks), heads, B);
   ProfScope ps(sizeof(T) == 2 ? "sf_attention_bf16" : "sf_attention_f32", 4.0 * B * (double)N * Nk * hidden,
                ((double)B * N * hidden * 2 + (double)B * Nk * hidden * 2) * sizeof(T), s);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, N, Nk, hidden, qblocks);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, N, Nk, hidden, qblocks, kv_ld);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }
@@ -872,10 +889,11 @@ int sf_head_fused(const void* f0, const void* w0, const void* g1, const void* g2
   return 0;
 }
 
-int sf_attention(int dtype, const void* q, const void* k, const void* v, void* out, int B, int N, int Nk, int hidden, hipStream_t s) {
+int sf_attention(int dtype, const void* q, const void* k, const void* v, void* out, int B, int N, int Nk, int hidden, int kv_ld, hipStream_t s) {
   if (hidden % 64 || Nk < 1 || Nk > 256 || (Nk % 16)) return -2;   // heads of 64 channels; keys in whole 16-key tiles, all in LDS
-  if (dtype == DT_F32) return attention_launch<float, 16>(q, k, v, out, B, N, Nk, hidden, s);
-  return attention_launch<bf16_t, 16>(q, k, v, out, B, N, Nk, hidden, s);
+  if (kv_ld < hidden || (kv_ld % (dtype == DT_F32 ? 4 : 8))) return -2;
+  if (dtype == DT_F32) return attention_launch<float, 16>(q, k, v, out, B, N, Nk, hidden, kv_ld, s);
+  return attention_launch<bf16_t, 16>(q, k, v, out, B, N, Nk, hidden, kv_ld, s);
 }
 
 }  // namespace flair
