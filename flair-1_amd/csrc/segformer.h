@@ -57,6 +57,7 @@ class SegFormer {
   const float* params_ = nullptr;
   std::vector<size_t> kv_w_;   // per block, in stage order: arena offset of the fused [k; v] packed weight, its concatenated bias
   std::vector<float*> kv_b_;
+  std::vector<float*> ffn_dw_;   // per block: regrouped depth-wise weights for the fused Mix-FFN kernel (null: not applicable)
   bool cache_ok_ = false;
   const float* cache_params_ = nullptr;
   const void* cache_ws_ = nullptr;

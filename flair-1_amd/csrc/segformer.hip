@@ -9,6 +9,8 @@
 // kernel of conv_igemm.hip with its fused epilogues (bias, residual add, folded BatchNorm + ReLU, fp32 NCHW logits).
 #include "segformer.h"
 
+#include <utility>
+
 #include <string.h>
 
 #include "segformer_ops.h"
@@ -204,6 +206,18 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
       }
     if (tb.n) SF_RUN(pack_weights_all(dtype, params_, base_, tb, s_));
   }
+  // depth-wise weights regrouped for the fused Mix-FFN kernel (stages of 64 / 128 channels, bf16)
+  ffn_dw_.clear();
+  for (size_t si = 0; si < stages.size(); ++si)
+    for (const SfBlock& K : stages[si].blocks) {
+      const int h = hidden[si];
+      float* p = nullptr;
+      if (dtype == DT_BF16 && (h == 64 || h == 128)) {
+        p = (float*)alloc((size_t)4 * h * 10 * 4);
+        if (!fresh) SF_RUN(sf_ffn_dw_pack(params_ + K.dw_w, params_ + K.dw_b, p, 4 * h, s_));
+      }
+      ffn_dw_.push_back(p);
+    }
   float* bn_scale = (float*)alloc((size_t)dec_hidden * 4);
   float* bn_shift = (float*)alloc((size_t)dec_hidden * 4);
   if (!fresh) SF_RUN(bn_eval_coeffs(dec_hidden, params_ + bn_g, params_ + bn_b, params_ + bn_rm, params_ + bn_rv, 1e-5f, bn_scale, bn_shift, s_));
@@ -310,10 +324,18 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
       ++blk;
       SF_RUN(sf_attention(dtype, qb, kvb, (const unsigned char*)kvb + (size_t)h * es, ctx, B, Hs * Ws, Hk * Wk, h, 2 * h, s_));
       gemm(lins[K.o], ctx, B, Hs, Ws, x, h, /*residual*/ x, nullptr, nullptr, 0, nullptr);   // x = o_proj(ctx) + x, element by element in place
-      layernorm(norms[K.ln2], x, ln, tokens);
-      gemm(lins[K.fc1], ln, B, Hs, Ws, f1, 4 * h, nullptr, nullptr, nullptr, 0, nullptr);
-      SF_RUN(sf_dwconv3x3_gelu(dtype, f1, params_ + K.dw_w, params_ + K.dw_b, f2, B, Hs, Ws, 4 * h, s_));
-      gemm(lins[K.fc2], f2, B, Hs, Ws, x, h, /*residual*/ x, nullptr, nullptr, 0, nullptr);
+      if (ffn_dw_[blk - 1] && sf_ffn_fused_ok(dtype, h, Hs, Ws) && tune("FLAIR_SF_FFN", 1)) {
+        // LayerNorm, fc1, depth-wise 3x3 + GELU, fc2 and the residual in one kernel; the result lands in the other buffer
+        const SfNorm& n2 = norms[K.ln2];
+        SF_RUN(sf_ffn_fused(x, params_ + n2.g_off, params_ + n2.b_off, base_ + lins[K.fc1].packed, params_ + lins[K.fc1].b_off, ffn_dw_[blk - 1],
+                            base_ + lins[K.fc2].packed, params_ + lins[K.fc2].b_off, ln, B, Hs, Ws, h, 1e-6f, s_));
+        std::swap(x, ln);
+      } else {
+        layernorm(norms[K.ln2], x, ln, tokens);
+        gemm(lins[K.fc1], ln, B, Hs, Ws, f1, 4 * h, nullptr, nullptr, nullptr, 0, nullptr);
+        SF_RUN(sf_dwconv3x3_gelu(dtype, f1, params_ + K.dw_w, params_ + K.dw_b, f2, B, Hs, Ws, 4 * h, s_));
+        gemm(lins[K.fc2], f2, B, Hs, Ws, x, h, /*residual*/ x, nullptr, nullptr, 0, nullptr);
+      }
     }
     layernorm(norms[S.out_ln], x, feat[i], tokens);
     top_ = mark;   // the stage's scratch is free again (one stream: later launches are ordered behind its readers)

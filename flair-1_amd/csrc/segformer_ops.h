@@ -14,6 +14,12 @@ int sf_fuse_bias(const float* wf, int D, const float* b3, const float* b2, const
                  const float* shift, float* shift2, hipStream_t s);
 int sf_upsample_sum_bn_relu(int dtype, const void* g0, const void* g1, const void* g2, const void* g3, const float* scale, const float* shift2,
                             void* z, int B, int H, int W, int D, hipStream_t s);
+// Mix-FFN of one block in one kernel (bf16, C = 64 / 128; see segformer_ops.hip): out = x + fc2(gelu(dwconv3x3(fc1(LayerNorm(x))))),
+// x / out [B][H][W][C] (different buffers), w1 [4C][C], w2 [C][4C] packed row-major, dwp from sf_ffn_dw_pack ([4C / 4][10][4] fp32)
+bool sf_ffn_fused_ok(int dtype, int C, int H, int W);
+int sf_ffn_dw_pack(const float* w, const float* b, float* out, int nch, hipStream_t s);
+int sf_ffn_fused(const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const float* dwp, const void* w2,
+                 const float* b2, void* out, int B, int H, int W, int C, float eps, hipStream_t s);
 // the whole decode head after the per-stage products in one kernel (bf16; see segformer_ops.hip): f0 [B][H][W][64], w0 [D][64],
 // g1..g3 [B][H >> i][W >> i][D], wint = the 128 x 96 interpolation matrix (sf_head_wint), wc [32][D] (rows >= labels zero), out fp32 NCHW
 bool sf_head_fused_ok(int dtype, int H, int W, int C0, int D, int labels);

@@ -539,6 +539,272 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const bf16_t* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------- Mix-FFN of a block in ONE kernel (bf16)
+// LayerNorm -> fc1 (C -> 4C) -> depth-wise 3x3 + GELU -> fc2 (4C -> C) -> + residual moves, as separate passes, the 4C-wide
+// intermediate through HBM four times (stage 0 at B = 32: 4 x 268 MB of the block's 2 GB).  All of it is local to a pixel tile
+// plus a one-pixel halo, so a workgroup takes an 8 x 8 tile of the token grid through the whole chain, 64 hidden channels at a
+// time, and the intermediate never leaves the CU:
+//   X halo tile (10 x 10 pixels x C) -> LDS, LayerNorm in place (two threads per pixel)
+//   per chunk of 64 hidden channels:  H1[ch][px] = W1 XN^T (+ bias, zero outside the image: the conv pads ITS input) -> LDS [px][64]
+//                                     A2 = gelu(dwconv3x3(H1)) on the vector pipe, sliding 3 x 6 windows                -> LDS [px][64]
+//                                     OUT[c][px] += W2[:, chunk] A2^T  (accumulators live across the chunks)
+//   x_out = OUT + bias + x
+// fc1 is recomputed on the halo (100 / 64 pixels); HBM traffic is x once (x 1.56) + x_out.  The chunk's weights (W1 rows, W2
+// columns, depth-wise taps, fc1 bias) go global -> registers -> LDS ONE CHUNK AHEAD, once per workgroup.  (First version: every
+// wave loaded its weight fragments straight from global memory inside the chunk loop — four copies of the same 30 KB per chunk
+// through the texture path and an L2 round trip per phase: 355 us per stage-0 block, 0.83 ms of a forward's 2.3 ms of fused FFN.)
+// The output is a DIFFERENT buffer than x: neighbouring tiles read each other's halo pixels.
+template <int C>
+struct FfnCfg {
+  static constexpr int XROW = C * 2 + 16, HPX = 100, HROWS = 112, ROW = 144;
+  static constexpr int OFF_H1 = HROWS * XROW, OFF_A2 = OFF_H1 + HROWS * ROW, OFF_W1 = OFF_A2 + 64 * ROW, OFF_B1 = OFF_W1 + 64 * XROW,
+                       OFF_W2 = OFF_B1 + 256, OFF_DW = OFF_W2 + C * ROW, SMEM = OFF_DW + 160 * 16;
+};
+
+// dw weights [4C][3][3] + bias [4C] -> [4C / 4][10][4]: per group of four channels nine tap vectors and the bias vector
+__global__ __launch_bounds__(256) void ffn_dw_pack_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out, int nch) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nch * 10) return;
+  const int e = i & 3, tp = (i >> 2) % 10, grp = i / 40;
+  const int ch = grp * 4 + e;
+  out[i] = tp < 9 ? w[ch * 9 + tp] : b[ch];
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                        const bf16_t* __restrict__ w1 /* [4C][C] */, const float* __restrict__ b1,
+                                                        const float* __restrict__ dwp /* [C][10][4] */, const bf16_t* __restrict__ w2 /* [C][4C] */,
+                                                        const float* __restrict__ b2, bf16_t* __restrict__ out, int B, int H, int W, float eps) {
+  using Cfg = FfnCfg<C>;
+  constexpr int XROW = Cfg::XROW, ROW = Cfg::ROW, CPR = C / 8, KS1 = C / 32, MT2 = C / 16, NCHUNK = 4 * C / 64, HID = 4 * C;
+  constexpr int NW = C / 32;   // 16-byte items per thread of a W1 / W2 chunk (64 rows x C, C rows x 64)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xs = smem;
+  unsigned char* h1 = smem + Cfg::OFF_H1;
+  unsigned char* a2 = smem + Cfg::OFF_A2;
+  unsigned char* w1s = smem + Cfg::OFF_W1;
+  unsigned char* b1s = smem + Cfg::OFF_B1;
+  unsigned char* w2s = smem + Cfg::OFF_W2;
+  unsigned char* dws = smem + Cfg::OFF_DW;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, g = lane >> 4;
+  const int tiles_x = W / 8, tiles_y = H / 8;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  const int x0 = tx * 8, y0 = ty * 8;
+  const bf16_t* xb = x + (long)b * H * W * C;
+  // ---- weight staging: registers of this thread for the next chunk
+  u32x4 rw1[NW], rw2[NW], rdw = u32x4{0u, 0u, 0u, 0u};
+  auto ld_w1 = [&](int hc) {   // + the chunk's fc1 bias (threads 160 .. 175) and depth-wise taps (threads < 160) ride along
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const int i = t + 256 * k, row = i / CPR, part = i - row * CPR;
+      rw1[k] = *reinterpret_cast<const u32x4*>(w1 + (long)(hc * 64 + row) * C + part * 8);
+    }
+    if (t < 160) rdw = *reinterpret_cast<const u32x4*>(dwp + ((long)hc * 160 + t) * 4);
+    else if (t < 176) rdw = *reinterpret_cast<const u32x4*>(b1 + hc * 64 + (t - 160) * 4);
+  };
+  auto st_w1 = [&]() {         // W1 rows + bias (read by fc1)
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const int i = t + 256 * k, row = i / CPR, part = i - row * CPR;
+      *reinterpret_cast<u32x4*>(w1s + row * XROW + part * 16) = rw1[k];
+    }
+    if (t >= 160 && t < 176) *reinterpret_cast<u32x4*>(b1s + (t - 160) * 16) = rdw;
+  };
+  auto st_dw = [&]() {         // depth-wise taps (read by the depth-wise phase)
+    if (t < 160) *reinterpret_cast<u32x4*>(dws + t * 16) = rdw;
+  };
+  auto ld_w2 = [&](int hc) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const int i = t + 256 * k, row = i >> 3, part = i & 7;
+      rw2[k] = *reinterpret_cast<const u32x4*>(w2 + (long)row * HID + hc * 64 + part * 8);
+    }
+  };
+  auto st_w2 = [&]() {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const int i = t + 256 * k, row = i >> 3, part = i & 7;
+      *reinterpret_cast<u32x4*>(w2s + row * ROW + part * 16) = rw2[k];
+    }
+  };
+  ld_w1(0);
+  ld_w2(0);
+  // ---- X halo tile -> LDS (zeros outside the image; rows 100 .. 111 are never consumed but must be finite); all loads of a
+  // thread are issued before the first LDS write
+  {
+    constexpr int NIT = (Cfg::HROWS * CPR + 255) / 256;
+    u32x4 v[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = t + 256 * k, hp = i / CPR, part = i - hp * CPR;
+      const int hy = hp / 10, hx = hp - hy * 10;
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      const bool ok = hp < Cfg::HPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const u32x4 ld = *reinterpret_cast<const u32x4*>(xb + (ok ? ((long)gy * W + gx) * C + part * 8 : 0));
+      v[k] = ok ? ld : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = t + 256 * k, hp = i / CPR, part = i - hp * CPR;
+      if (i < Cfg::HROWS * CPR) *reinterpret_cast<u32x4*>(xs + hp * XROW + part * 16) = v[k];
+    }
+  }
+  st_w1();
+  st_dw();
+  __syncthreads();
+  // ---- LayerNorm in place, TWO threads per halo pixel, each half of the channels (mean, biased variance of the centred values,
+  // eps inside the root); the halves meet through a lane shuffle
+  {
+    const int hp = t >> 1, half = t & 1;
+    const bool live = hp < Cfg::HPX;
+    unsigned char* row = xs + (live ? hp : 0) * XROW + half * (C / 2) * 2;
+    constexpr int HC = CPR / 2;   // 16-byte chunks per half row
+    float f[HC][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < HC; ++c) {
+      chunk_to_f<bf16_t>(*reinterpret_cast<const uint4*>(row + c * 16), f[c]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += f[c][e];
+    }
+    sum += __shfl_xor(sum, 1);
+    const float mean = sum / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < HC; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[c][e] - mean; q = fmaf(d, d, q); }
+    q += __shfl_xor(q, 1);
+    const float rstd = 1.f / sqrtf(q / (float)C + eps);
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < HC; ++c) {
+        const int c0 = half * (C / 2) + c * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[c][e] = fmaf((f[c][e] - mean) * rstd, ln_g[c0 + e], ln_b[c0 + e]);
+        *reinterpret_cast<uint4*>(row + c * 16) = f_to_chunk<bf16_t>(f[c]);
+      }
+    }
+  }
+  // ---- per-lane constants: which of this wave's fc1 pixel tiles (wave, wave + 4) hold in-image pixels
+  bool inimg[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int hp = (wave + 4 * k) * 16 + lr, hy = hp / 10, hx = hp - hy * 10;
+    inimg[k] = hp < Cfg::HPX && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+  }
+  const int npt = wave < 3 ? 2 : 1;                  // 7 pixel tiles of 16 halo rows over 4 waves
+  // depth-wise item of this thread: channel group gq (4 channels), row py, half xh (4 pixels)
+  const int gq = t & 15, seg = t >> 4, py = seg >> 1, xh = seg & 1;
+  f32x4_t acc2[MT2];
+#pragma unroll
+  for (int m = 0; m < MT2; ++m) acc2[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (int hc = 0; hc < NCHUNK; ++hc) {
+    // rw2 holds W2's chunk hc (loaded a chunk ago); the next chunk's W1 / bias / taps start their trip now
+    if (hc + 1 < NCHUNK) ld_w1(hc + 1);
+    // ---- fc1 on the halo: H1[ch][px], this wave's pixel tiles x the chunk's four 16-channel tiles
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k < npt) {   // wave-uniform
+        const int pt = wave + 4 * k;
+        u32x4 bx[KS1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) bx[ks] = *reinterpret_cast<const u32x4*>(xs + (pt * 16 + lr) * XROW + (ks * 32 + 8 * g) * 2);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS1; ++ks) {
+            const u32x4 wf = *reinterpret_cast<const u32x4*>(w1s + (ct * 16 + lr) * XROW + (ks * 32 + 8 * g) * 2);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, bx[ks]), a, 0, 0, 0);
+          }
+          const float4 bb = *reinterpret_cast<const float4*>(b1s + (ct * 16 + 4 * g) * 4);
+          const float v0 = inimg[k] ? a[0] + bb.x : 0.f, v1 = inimg[k] ? a[1] + bb.y : 0.f;
+          const float v2 = inimg[k] ? a[2] + bb.z : 0.f, v3 = inimg[k] ? a[3] + bb.w : 0.f;
+          uint2 pk;
+          pk.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+          pk.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+          *reinterpret_cast<uint2*>(h1 + (pt * 16 + lr) * ROW + (ct * 16 + 4 * g) * 2) = pk;
+        }
+      }
+    }
+    __syncthreads();                                 // H1 complete; every wave is past fc1 (W1 / bias image free), fc2 of hc - 1 (W2 free)
+    st_w2();                                         // W2 chunk hc for this chunk's fc2
+    if (hc + 1 < NCHUNK) ld_w2(hc + 1);
+    // ---- depth-wise 3 x 3 + GELU: four outputs along x from a sliding 3 x 6 window of H1 (halo rows py .. py + 2)
+    {
+      float4 dw[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) dw[k] = *reinterpret_cast<const float4*>(dws + (gq * 10 + k) * 16);
+      float win[3][3][4];
+      auto rd = [&](int slot, int col) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const uint2 v = *reinterpret_cast<const uint2*>(h1 + ((py + r) * 10 + xh * 4 + col) * ROW + gq * 8);
+          win[slot][r][0] = __uint_as_float(v.x << 16); win[slot][r][1] = __uint_as_float(v.x & 0xffff0000u);
+          win[slot][r][2] = __uint_as_float(v.y << 16); win[slot][r][3] = __uint_as_float(v.y & 0xffff0000u);
+        }
+      };
+      rd(0, 0);
+      rd(1, 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rd((i + 2) % 3, i + 2);
+        float o[4] = {dw[9].x, dw[9].y, dw[9].z, dw[9].w};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int qq = 0; qq < 3; ++qq) {
+            const float4 wv = dw[r * 3 + qq];
+            const float* xv = win[(i + qq) % 3][r];
+            o[0] = fmaf(xv[0], wv.x, o[0]); o[1] = fmaf(xv[1], wv.y, o[1]); o[2] = fmaf(xv[2], wv.z, o[2]); o[3] = fmaf(xv[3], wv.w, o[3]);
+          }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gelu_erf<bf16_t>(o[e]);
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+        *reinterpret_cast<uint2*>(a2 + (py * 8 + xh * 4 + i) * ROW + gq * 8) = pk;
+      }
+    }
+    if (hc + 1 < NCHUNK) st_w1();                    // next chunk's W1 rows + bias (their readers start behind the barrier below)
+    __syncthreads();                                 // A2 and W2 complete; every wave is past the depth-wise phase (tap image free)
+    if (hc + 1 < NCHUNK) st_dw();
+    // ---- fc2: OUT[c][px] += W2[:, chunk] A2^T, this wave's 16 pixels
+    {
+      u32x4 ba[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) ba[ks] = *reinterpret_cast<const u32x4*>(a2 + (wave * 16 + lr) * ROW + (ks * 32 + 8 * g) * 2);
+#pragma unroll
+      for (int m = 0; m < MT2; ++m)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x4 wf = *reinterpret_cast<const u32x4*>(w2s + (m * 16 + lr) * ROW + (ks * 32 + 8 * g) * 2);
+          acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, ba[ks]), acc2[m], 0, 0, 0);
+        }
+    }
+    // (no barrier here: the next writers of H1 / A2 / W2 sit behind the next chunk's first barrier)
+  }
+  // ---- x_out = OUT + b2 + x: lane holds channels 16 m + 4 g .. + 3 of pixel (wave * 16 + lr)
+  {
+    const int p = wave * 16 + lr, gy = y0 + (p >> 3), gx = x0 + (p & 7);
+    const long base = (((long)b * H + gy) * W + gx) * C;
+#pragma unroll
+    for (int m = 0; m < MT2; ++m) {
+      const int c = m * 16 + 4 * g;
+      const uint2 rv = *reinterpret_cast<const uint2*>(x + base + c);
+      const float4 bb = *reinterpret_cast<const float4*>(b2 + c);
+      const float r0 = __uint_as_float(rv.x << 16), r1 = __uint_as_float(rv.x & 0xffff0000u);
+      const float r2 = __uint_as_float(rv.y << 16), r3 = __uint_as_float(rv.y & 0xffff0000u);
+      uint2 pk;
+      pk.x = (unsigned)f32_to_bf16(acc2[m][0] + bb.x + r0) | ((unsigned)f32_to_bf16(acc2[m][1] + bb.y + r1) << 16);
+      pk.y = (unsigned)f32_to_bf16(acc2[m][2] + bb.z + r2) | ((unsigned)f32_to_bf16(acc2[m][3] + bb.w + r3) << 16);
+      *reinterpret_cast<uint2*>(out + base + c) = pk;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------ attention
 // softmax(Q K^T / 8) V for one head of 64 channels, keys / values = the spatially reduced sequence (Nk <= 256 tokens), whole
 // in LDS: K as [key][64] rows, V transposed to [64][key].  The scores are computed TRANSPOSED, S^T = K Q^T, so that a lane
@@ -864,6 +1130,43 @@ int sf_upsample_sum_bn_relu(int dtype, const void* g0, const void* g1, const voi
                        (const bf16_t*)g2, (const bf16_t*)g3, scale, shift2, (bf16_t*)z, B, H, W, D);
   FLAIR_CHECK_LAUNCH();
   return 0;
+}
+
+int sf_ffn_dw_pack(const float* w, const float* b, float* out, int nch, hipStream_t s) {
+  if (nch % 4) return -2;
+  hipLaunchKernelGGL(ffn_dw_pack_kernel, dim3((nch * 10 + 255) / 256), dim3(256), 0, s, w, b, out, nch);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+bool sf_ffn_fused_ok(int dtype, int C, int H, int W) {
+  return dtype == DT_BF16 && (C == 64 || C == 128) && H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8;
+}
+
+template <int C>
+static int ffn_fused_launch(const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const float* dwp, const void* w2,
+                            const float* b2, void* out, int B, int H, int W, float eps, hipStream_t s) {
+  auto kern = ffn_fused_kernel<C>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FfnCfg<C>::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long tiles = (long)B * (H / 8) * (W / 8);
+  if (tiles > (1L << 30)) return -2;
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), FfnCfg<C>::SMEM, s, (const bf16_t*)x, ln_g, ln_b, (const bf16_t*)w1, b1, dwp,
+                     (const bf16_t*)w2, b2, (bf16_t*)out, B, H, W, eps);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int sf_ffn_fused(const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const float* dwp, const void* w2,
+                 const float* b2, void* out, int B, int H, int W, int C, float eps, hipStream_t s) {
+  if (!sf_ffn_fused_ok(DT_BF16, C, H, W) || x == out) return -2;
+  ProfScope ps("sf_ffn_fused", 2.0 * B * H * W * C * 4.0 * C * 2.0 + 18.0 * B * H * W * 4.0 * C, 2.0 * B * H * W * C * 2.0, s);
+  return C == 64 ? ffn_fused_launch<64>(x, ln_g, ln_b, w1, b1, dwp, w2, b2, out, B, H, W, eps, s)
+                 : ffn_fused_launch<128>(x, ln_g, ln_b, w1, b1, dwp, w2, b2, out, B, H, W, eps, s);
 }
 
 int sf_head_wint(void* wint, hipStream_t s) {

@@ -103,6 +103,34 @@ def test_fused_decode_head_kernel_matches_the_separate_passes_bf16(dev, shape):
     assert float((fused - want).abs().max()) < 3e-2 * scale and float((fused - want).pow(2).mean().sqrt()) < 6e-3 * scale
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 128), (1, 128, 128), (1, 512, 512)])
+def test_fused_mix_ffn_kernel_matches_the_separate_passes_bf16(dev, shape):
+    """bf16 runs LayerNorm -> fc1 -> depth-wise 3x3 + GELU -> fc2 -> + residual of the 64- and 128-channel stages in one kernel per
+    block (ffn_fused_kernel: 8 x 8 token tiles with a recomputed one-pixel halo, the 4C-wide intermediate stays in LDS).
+    FLAIR_SF_FFN=0 runs the four separate passes.  Both round the same intermediates to bf16 (LayerNorm output, fc1 output, GELU
+    output, the block's result), so they differ by summation order and the bf16 roundings it flips, through 7 blocks; image-edge
+    tiles (zero padding of the depth-wise conv's input), a non-square grid and the 128 x 128 minimum are in the shapes."""
+    from flair_amd import _lib as L
+    from oracle import parity
+    from oracle import segformer as osf
+    ref, hip = _pair(dev, "bf16")
+    x = torch.randn(*[shape[0], 5, shape[1], shape[2]], generator=torch.Generator().manual_seed(22))
+    fused = hip(x.to(dev)).logits.cpu()
+    try:
+        L.check(L.lib().flair_tune_set(b"FLAIR_SF_FFN", 0))
+        sep = hip(x.to(dev)).logits.cpu()
+    finally:
+        L.lib().flair_tune_set(b"FLAIR_SF_FFN", 1)
+    want = osf.logits(ref, x)[0]
+    scale = float(want.abs().max())
+    d = (fused - sep).abs()
+    parity.record({"test": f"segformer_fused_ffn_{shape[0]}x{shape[1]}x{shape[2]}", "logit_scale": scale, "max_abs": float(d.max()),
+                   "rms": float(d.pow(2).mean().sqrt()), "fused_vs_oracle_max": float((fused - want).abs().max()),
+                   "separate_vs_oracle_max": float((sep - want).abs().max())})
+    assert float(d.max()) < 2e-2 * scale and float(d.pow(2).mean().sqrt()) < 3e-3 * scale
+    assert float((fused - want).abs().max()) < 3e-2 * scale and float((fused - want).pow(2).mean().sqrt()) < 6e-3 * scale
+
+
 def test_bf16_mode_tracks_the_oracle(dev):
     """bf16 throughput mode: the logit-error rule of oracle/parity.py (measured: max |dlogit| 1.0e-2 and rms 1.9e-3 of the
     logit scale at 512x512, profiles/r3_parity.json; bounds 3x)."""
