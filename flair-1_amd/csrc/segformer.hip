@@ -304,12 +304,20 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
     // overlapping patch embedding (strided convolution + bias), LayerNorm
     gemm(lins[S.patch], sin, B, sH, sW, ln, h, nullptr, nullptr, nullptr, 0, nullptr);
     layernorm(norms[S.patch_ln], ln, x, tokens);
-    for (const SfBlock& K : S.blocks) {
-      layernorm(norms[K.ln1], x, ln, tokens);
-      gemm(lins[K.q], ln, B, Hs, Ws, qb, h, nullptr, nullptr, nullptr, 0, nullptr);
-      const void* kv_in = ln;
+    const void* ln1_done = nullptr;   // layernorm_before of the coming block, already written by the previous block's fused FFN
+    bool stage_norm_done = false;
+    for (size_t bi = 0; bi < S.blocks.size(); ++bi) {
+      const SfBlock& K = S.blocks[bi];
+      const void* lnin = ln1_done;
+      if (!lnin) {
+        layernorm(norms[K.ln1], x, ln, tokens);
+        lnin = ln;
+      }
+      ln1_done = nullptr;
+      gemm(lins[K.q], lnin, B, Hs, Ws, qb, h, nullptr, nullptr, nullptr, 0, nullptr);
+      const void* kv_in = lnin;
       if (K.sr >= 0) {   // sequence reduction: sr x sr convolution of stride sr over the token grid, LayerNorm
-        gemm(lins[K.sr], ln, B, Hs, Ws, red, h, nullptr, nullptr, nullptr, 0, nullptr);
+        gemm(lins[K.sr], lnin, B, Hs, Ws, red, h, nullptr, nullptr, nullptr, 0, nullptr);
         layernorm(norms[K.sr_ln], red, redn, ktok);
         kv_in = redn;
       }
@@ -326,10 +334,20 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
       gemm(lins[K.o], ctx, B, Hs, Ws, x, h, /*residual*/ x, nullptr, nullptr, 0, nullptr);   // x = o_proj(ctx) + x, element by element in place
       if (ffn_dw_[blk - 1] && sf_ffn_fused_ok(dtype, h, Hs, Ws) && tune("FLAIR_SF_FFN", 1)) {
         // LayerNorm, fc1, depth-wise 3x3 + GELU, fc2 and the residual in one kernel; the result lands in the other buffer
+        // ... and the LayerNorm that FOLLOWS the block from the same registers: the next block's layernorm_before (into ctx: free
+        // until that block's attention writes it, by when its readers — q and the sequence reduction — are done) or the stage's
+        // final norm (into the feature map).  K.sr >= 0 in these stages, so nothing else reads layernorm_before's output.
         const SfNorm& n2 = norms[K.ln2];
+        const bool last = bi + 1 == S.blocks.size();
+        const bool emit = K.sr >= 0 && tune("FLAIR_SF_FFN_LN", 1);
+        const SfNorm& nn = norms[last ? S.out_ln : S.blocks[bi + 1].ln1];
+        void* lnout = emit ? (last ? feat[i] : ctx) : nullptr;
         SF_RUN(sf_ffn_fused(x, params_ + n2.g_off, params_ + n2.b_off, base_ + lins[K.fc1].packed, params_ + lins[K.fc1].b_off, ffn_dw_[blk - 1],
-                            base_ + lins[K.fc2].packed, params_ + lins[K.fc2].b_off, ln, B, Hs, Ws, h, 1e-6f, s_));
+                            base_ + lins[K.fc2].packed, params_ + lins[K.fc2].b_off, ln, B, Hs, Ws, h, 1e-6f, params_ + nn.g_off,
+                            params_ + nn.b_off, lnout, s_));
         std::swap(x, ln);
+        if (emit && last) stage_norm_done = true;
+        else if (emit) ln1_done = ctx;
       } else {
         layernorm(norms[K.ln2], x, ln, tokens);
         gemm(lins[K.fc1], ln, B, Hs, Ws, f1, 4 * h, nullptr, nullptr, nullptr, 0, nullptr);
@@ -337,7 +355,7 @@ int SegFormer::run(const float* params, const float* x_nchw, float* logits_quart
         gemm(lins[K.fc2], f2, B, Hs, Ws, x, h, /*residual*/ x, nullptr, nullptr, 0, nullptr);
       }
     }
-    layernorm(norms[S.out_ln], x, feat[i], tokens);
+    if (!stage_norm_done) layernorm(norms[S.out_ln], x, feat[i], tokens);
     top_ = mark;   // the stage's scratch is free again (one stream: later launches are ordered behind its readers)
     sin = feat[i]; sH = Hs; sW = Ws;
   }

@@ -18,8 +18,10 @@ int sf_upsample_sum_bn_relu(int dtype, const void* g0, const void* g1, const voi
 // x / out [B][H][W][C] (different buffers), w1 [4C][C], w2 [C][4C] packed row-major, dwp from sf_ffn_dw_pack ([4C / 4][10][4] fp32)
 bool sf_ffn_fused_ok(int dtype, int C, int H, int W);
 int sf_ffn_dw_pack(const float* w, const float* b, float* out, int nch, hipStream_t s);
+// out_ln (optional, not x): LayerNorm(out) with ln2_g / ln2_b — the norm that follows the block, from the epilogue's registers
 int sf_ffn_fused(const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const float* dwp, const void* w2,
-                 const float* b2, void* out, int B, int H, int W, int C, float eps, hipStream_t s);
+                 const float* b2, void* out, int B, int H, int W, int C, float eps, const float* ln2_g, const float* ln2_b, void* out_ln,
+                 hipStream_t s);
 // the whole decode head after the per-stage products in one kernel (bf16; see segformer_ops.hip): f0 [B][H][W][64], w0 [D][64],
 // g1..g3 [B][H >> i][W >> i][D], wint = the 128 x 96 interpolation matrix (sf_head_wint), wc [32][D] (rows >= labels zero), out fp32 NCHW
 bool sf_head_fused_ok(int dtype, int H, int W, int C0, int D, int labels);

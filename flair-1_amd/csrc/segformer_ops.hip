@@ -574,7 +574,9 @@ template <int C>
 __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                         const bf16_t* __restrict__ w1 /* [4C][C] */, const float* __restrict__ b1,
                                                         const float* __restrict__ dwp /* [C][10][4] */, const bf16_t* __restrict__ w2 /* [C][4C] */,
-                                                        const float* __restrict__ b2, bf16_t* __restrict__ out, int B, int H, int W, float eps) {
+                                                        const float* __restrict__ b2, bf16_t* __restrict__ out, int B, int H, int W, float eps,
+                                                        const float* __restrict__ ln2_g, const float* __restrict__ ln2_b,
+                                                        bf16_t* __restrict__ out_ln /* optional: LayerNorm(out) with ln2_*, the next consumer's input */) {
   using Cfg = FfnCfg<C>;
   constexpr int XROW = Cfg::XROW, ROW = Cfg::ROW, CPR = C / 8, KS1 = C / 32, MT2 = C / 16, NCHUNK = 4 * C / 64, HID = 4 * C;
   constexpr int NW = C / 32;   // 16-byte items per thread of a W1 / W2 chunk (64 rows x C, C rows x 64)
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict
   {
     const int p = wave * 16 + lr, gy = y0 + (p >> 3), gx = x0 + (p & 7);
     const long base = (((long)b * H + gy) * W + gx) * C;
+    float xo[MT2][4];
 #pragma unroll
     for (int m = 0; m < MT2; ++m) {
       const int c = m * 16 + 4 * g;
@@ -801,6 +804,36 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict
       pk.x = (unsigned)f32_to_bf16(acc2[m][0] + bb.x + r0) | ((unsigned)f32_to_bf16(acc2[m][1] + bb.y + r1) << 16);
       pk.y = (unsigned)f32_to_bf16(acc2[m][2] + bb.z + r2) | ((unsigned)f32_to_bf16(acc2[m][3] + bb.w + r3) << 16);
       *reinterpret_cast<uint2*>(out + base + c) = pk;
+      // the stored (rounded) values: what a separate LayerNorm pass would read back
+      xo[m][0] = __uint_as_float(pk.x << 16); xo[m][1] = __uint_as_float(pk.x & 0xffff0000u);
+      xo[m][2] = __uint_as_float(pk.y << 16); xo[m][3] = __uint_as_float(pk.y & 0xffff0000u);
+    }
+    // ---- the LayerNorm that follows the block (next block's layernorm_before, or the stage's final norm): the C channels of a
+    // pixel sit in this lane's registers and in the three lanes lr + 16, + 32, + 48 — two shuffles per reduction
+    if (out_ln) {   // workgroup-uniform
+      float sum = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT2; ++m) sum += (xo[m][0] + xo[m][1]) + (xo[m][2] + xo[m][3]);
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum / (float)C;
+      float q2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT2; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xo[m][e] - mean; q2 = fmaf(d, d, q2); }
+      q2 += __shfl_xor(q2, 16);
+      q2 += __shfl_xor(q2, 32);
+      const float rstd = 1.f / sqrtf(q2 / (float)C + eps);
+#pragma unroll
+      for (int m = 0; m < MT2; ++m) {
+        const int c = m * 16 + 4 * g;
+        const float4 gg = *reinterpret_cast<const float4*>(ln2_g + c), be = *reinterpret_cast<const float4*>(ln2_b + c);
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(fmaf((xo[m][0] - mean) * rstd, gg.x, be.x)) | ((unsigned)f32_to_bf16(fmaf((xo[m][1] - mean) * rstd, gg.y, be.y)) << 16);
+        pk.y = (unsigned)f32_to_bf16(fmaf((xo[m][2] - mean) * rstd, gg.z, be.z)) | ((unsigned)f32_to_bf16(fmaf((xo[m][3] - mean) * rstd, gg.w, be.w)) << 16);
+        *reinterpret_cast<uint2*>(out_ln + base + c) = pk;
+      }
     }
   }
 }
@@ -1145,7 +1178,8 @@ bool sf_ffn_fused_ok(int dtype, int C, int H, int W) {
 
 template <int C>
 static int ffn_fused_launch(const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const float* dwp, const void* w2,
-                            const float* b2, void* out, int B, int H, int W, float eps, hipStream_t s) {
+                            const float* b2, void* out, int B, int H, int W, float eps, const float* ln2_g, const float* ln2_b, void* out_ln,
+                            hipStream_t s) {
   auto kern = ffn_fused_kernel<C>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1156,17 +1190,18 @@ static int ffn_fused_launch(const void* x, const float* ln_g, const float* ln_b,
   const long tiles = (long)B * (H / 8) * (W / 8);
   if (tiles > (1L << 30)) return -2;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), FfnCfg<C>::SMEM, s, (const bf16_t*)x, ln_g, ln_b, (const bf16_t*)w1, b1, dwp,
-                     (const bf16_t*)w2, b2, (bf16_t*)out, B, H, W, eps);
+                     (const bf16_t*)w2, b2, (bf16_t*)out, B, H, W, eps, ln2_g, ln2_b, (bf16_t*)out_ln);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }
 
 int sf_ffn_fused(const void* x, const float* ln_g, const float* ln_b, const void* w1, const float* b1, const float* dwp, const void* w2,
-                 const float* b2, void* out, int B, int H, int W, int C, float eps, hipStream_t s) {
-  if (!sf_ffn_fused_ok(DT_BF16, C, H, W) || x == out) return -2;
+                 const float* b2, void* out, int B, int H, int W, int C, float eps, const float* ln2_g, const float* ln2_b, void* out_ln,
+                 hipStream_t s) {
+  if (!sf_ffn_fused_ok(DT_BF16, C, H, W) || x == out || out_ln == x || (out_ln && (!ln2_g || !ln2_b))) return -2;
   ProfScope ps("sf_ffn_fused", 2.0 * B * H * W * C * 4.0 * C * 2.0 + 18.0 * B * H * W * 4.0 * C, 2.0 * B * H * W * C * 2.0, s);
-  return C == 64 ? ffn_fused_launch<64>(x, ln_g, ln_b, w1, b1, dwp, w2, b2, out, B, H, W, eps, s)
-                 : ffn_fused_launch<128>(x, ln_g, ln_b, w1, b1, dwp, w2, b2, out, B, H, W, eps, s);
+  return C == 64 ? ffn_fused_launch<64>(x, ln_g, ln_b, w1, b1, dwp, w2, b2, out, B, H, W, eps, ln2_g, ln2_b, out_ln, s)
+                 : ffn_fused_launch<128>(x, ln_g, ln_b, w1, b1, dwp, w2, b2, out, B, H, W, eps, ln2_g, ln2_b, out_ln, s);
 }
 
 int sf_head_wint(void* wint, hipStream_t s) {
