@@ -1017,6 +1017,178 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
   }
 }
 
+// bf16 form with TWO query tiles per wave and the keys in halves of 128 (online softmax across the halves): every K / V^T
+// fragment read from LDS feeds two MFMAs.  The one-tile form above re-read all of K and V^T (69 KB) per 16 queries — 96 LDS
+// reads per 64 MFMAs, eight waves of a CU queueing on one LDS: ~6k LDS cycles per round against 2k of matrix issue.  Scores stay
+// in the log2 domain (one fused multiply-add + v_exp per score).
+__global__ __launch_bounds__(256) void attention2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                         bf16_t* __restrict__ out, int N, int Nk, int hidden, int qblocks, int kv_ld) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int KROW = AttCfg<bf16_t>::KROW, VROW = AttCfg<bf16_t>::vrow(Nk);
+  unsigned char* ks = smem;
+  unsigned char* vt = smem + (size_t)Nk * KROW;
+  const bf16_t* kb = k + ((long)b * Nk) * kv_ld + head * 64;
+  const bf16_t* vb = v + ((long)b * Nk) * kv_ld + head * 64;
+  for (int i = t; i < Nk * 8; i += 256) {
+    const int key = i >> 3, c = i & 7;
+    *reinterpret_cast<uint4*>(ks + key * KROW + c * 16) = *reinterpret_cast<const uint4*>(kb + (long)key * kv_ld + c * 8);
+    const uint4 vv = *reinterpret_cast<const uint4*>(vb + (long)key * kv_ld + c * 8);
+    const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16_t*>(vt + (c * 8 + e) * VROW + key * 2) = ve[e];
+  }
+  __syncthreads();
+  const float cs = 0.125f * 1.4426950408889634f;   // 64 ** -0.5 * log2(e)
+  const int nhalf = (Nk + 127) >> 7;
+  auto q_ptr = [&](int qb, int qt) {
+    const int q0 = (blockIdx.x * qblocks + qb) * 128 + wave * 32 + qt * 16;
+    const int qi = q0 + lr < N ? q0 + lr : N - 1;   // ragged tail: clamp, masked at the store
+    return q + ((long)b * N + qi) * hidden + head * 64;
+  };
+  u32x4 qn[2][2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const bf16_t* qp = q_ptr(0, qt);
+    qn[qt][0] = *reinterpret_cast<const u32x4*>(qp + 8 * g);
+    qn[qt][1] = *reinterpret_cast<const u32x4*>(qp + 32 + 8 * g);
+  }
+  for (int qb = 0; qb < qblocks; ++qb) {
+    const int q0 = (blockIdx.x * qblocks + qb) * 128 + wave * 32;
+    if (q0 >= N) break;   // wave-uniform
+    u32x4 qf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) { qf[qt][0] = qn[qt][0]; qf[qt][1] = qn[qt][1]; }
+    if (qb + 1 < qblocks) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const bf16_t* qp = q_ptr(qb + 1, qt);
+        qn[qt][0] = *reinterpret_cast<const u32x4*>(qp + 8 * g);
+        qn[qt][1] = *reinterpret_cast<const u32x4*>(qp + 32 + 8 * g);
+      }
+    }
+    float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+    f32x4_t o[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < nhalf; ++h) {
+      const int key0 = h * 128;
+      f32x4_t acc[8][2];
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        acc[kt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        acc[kt][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (key0 + kt * 16 < Nk) {
+          const unsigned char* kr = ks + (key0 + kt * 16 + lr) * KROW + 16 * g;
+          const u32x4 a0 = *reinterpret_cast<const u32x4*>(kr), a1 = *reinterpret_cast<const u32x4*>(kr + 64);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a0), __builtin_bit_cast(bf16x8_t, qf[qt][0]), acc[kt][qt], 0, 0, 0);
+            acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, qf[qt][1]), acc[kt][qt], 0, 0, 0);
+          }
+        }
+      }
+      // ---- online softmax of this half, per query tile (rows 4 g + r of every key tile; lane groups g share a query)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+          if (key0 + kt * 16 < Nk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[kt][qt][r]);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(mrun[qt], mx * cs);
+        const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);   // first half: exp2(-inf) = 0 on zeros
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+          if (key0 + kt * 16 < Nk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[kt][qt][r] = __builtin_amdgcn_exp2f(fmaf(acc[kt][qt][r], cs, -mnew)); ps += acc[kt][qt][r]; }
+          }
+        lrun[qt] = fmaf(lrun[qt], alpha, ps);
+        mrun[qt] = mnew;
+        if (h > 0) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+        }
+      }
+      // ---- O^T += V^T P^T: 32 keys per step; slots j < 4 <- tile 2 s row 4 g + j, j >= 4 <- tile 2 s + 1 row 4 g + j - 4
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        if (key0 + s2 * 32 < Nk) {
+          const bool two = key0 + s2 * 32 + 16 < Nk;
+          u32x4 pf[2];
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            pf[qt].x = (unsigned)f32_to_bf16(acc[2 * s2][qt][0]) | ((unsigned)f32_to_bf16(acc[2 * s2][qt][1]) << 16);
+            pf[qt].y = (unsigned)f32_to_bf16(acc[2 * s2][qt][2]) | ((unsigned)f32_to_bf16(acc[2 * s2][qt][3]) << 16);
+            pf[qt].z = two ? ((unsigned)f32_to_bf16(acc[2 * s2 + 1][qt][0]) | ((unsigned)f32_to_bf16(acc[2 * s2 + 1][qt][1]) << 16)) : 0u;
+            pf[qt].w = two ? ((unsigned)f32_to_bf16(acc[2 * s2 + 1][qt][2]) | ((unsigned)f32_to_bf16(acc[2 * s2 + 1][qt][3]) << 16)) : 0u;
+          }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const unsigned char* vr = vt + (dt * 16 + lr) * VROW + (key0 + s2 * 32 + 4 * g) * 2;
+            const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+            const uint2 hi = two ? *reinterpret_cast<const uint2*>(vr + 32) : make_uint2(0u, 0u);
+            const u32x4 vf = u32x4{lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+              o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[qt]), o[qt][dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float l = lrun[qt];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv = 1.f / l;
+      const int qi = q0 + qt * 16 + lr;
+      if (qi < N) {
+        bf16_t* op = out + ((long)b * N + qi) * hidden + head * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          uint2 pk;
+          pk.x = (unsigned)f32_to_bf16(o[qt][dt][0] * inv) | ((unsigned)f32_to_bf16(o[qt][dt][1] * inv) << 16);
+          pk.y = (unsigned)f32_to_bf16(o[qt][dt][2] * inv) | ((unsigned)f32_to_bf16(o[qt][dt][3] * inv) << 16);
+          *reinterpret_cast<uint2*>(op + dt * 16) = pk;
+        }
+      }
+    }
+  }
+}
+
+static int attention2_launch(const void* q, const void* k, const void* v, void* out, int B, int N, int Nk, int hidden, int kv_ld, hipStream_t s) {
+  const int smem = Nk * AttCfg<bf16_t>::KROW + 64 * AttCfg<bf16_t>::vrow(Nk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int most = 256 * AttCfg<bf16_t>::KROW + 64 * AttCfg<bf16_t>::vrow(256);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int heads = hidden / 64;
+  int qblocks = 1;
+  while (qblocks < 4 && (long)((N + 128 * qblocks * 2 - 1) / (128 * qblocks * 2)) * heads * B >= 512) qblocks *= 2;
+  dim3 grid((N + 128 * qblocks - 1) / (128 * qblocks), heads, B);
+  ProfScope ps("sf_attention_bf16", 4.0 * B * (double)N * Nk * hidden, ((double)B * N * hidden * 2 + (double)B * Nk * hidden * 2) * 2, s);
+  hipLaunchKernelGGL(attention2_kernel, grid, dim3(256), smem, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, N, Nk, hidden,
+                     qblocks, kv_ld);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
 static inline int ew_blocks(long total) {
   long b = (total + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
@@ -1231,6 +1403,7 @@ int sf_attention(int dtype, const void* q, const void* k, const void* v, void* o
   if (hidden % 64 || Nk < 1 || Nk > 256 || (Nk % 16)) return -2;   // heads of 64 channels; keys in whole 16-key tiles, all in LDS
   if (kv_ld < hidden || (kv_ld % (dtype == DT_F32 ? 4 : 8))) return -2;
   if (dtype == DT_F32) return attention_launch<float, 16>(q, k, v, out, B, N, Nk, hidden, kv_ld, s);
+  if (tune("FLAIR_SF_ATT2", 1)) return attention2_launch(q, k, v, out, B, N, Nk, hidden, kv_ld, s);
   return attention_launch<bf16_t, 16>(q, k, v, out, B, N, Nk, hidden, kv_ld, s);
 }
 

@@ -131,17 +131,37 @@ def test_fused_mix_ffn_kernel_matches_the_separate_passes_bf16(dev, shape):
     assert float((fused - want).abs().max()) < 3e-2 * scale and float((fused - want).pow(2).mean().sqrt()) < 6e-3 * scale
 
 
-def test_bf16_mode_tracks_the_oracle(dev):
+@pytest.mark.parametrize("side", [512, 384])
+def test_bf16_mode_tracks_the_oracle(dev, side):
     """bf16 throughput mode: the logit-error rule of oracle/parity.py (measured: max |dlogit| 1.0e-2 and rms 1.9e-3 of the
-    logit scale at 512x512, profiles/r3_parity.json; bounds 3x)."""
+    logit scale at 512x512, profiles/r3_parity.json; bounds 3x).  384 x 384 has 144 reduced keys: the attention kernel's second
+    half of keys (online softmax across halves of 128) holds a single 16-key tile."""
     from oracle import parity
     from oracle import segformer as osf
     ref, hip = _pair(dev, "bf16")
-    x = torch.randn(1, 5, 512, 512, generator=torch.Generator().manual_seed(3))
+    x = torch.randn(1, 5, side, side, generator=torch.Generator().manual_seed(3))
     _, lf = osf.logits(ref, x)
     gf = hip.forward_full(x.to(dev)).cpu()
-    parity.assert_masks_within_logit_error("segformer_b2_bf16_1x512", lf.numpy(), gf.numpy(), gf.argmax(1).numpy(),
+    parity.assert_masks_within_logit_error(f"segformer_b2_bf16_1x{side}", lf.numpy(), gf.numpy(), gf.argmax(1).numpy(),
                                            max_rel_dlogit=3e-2, max_rel_rms=6e-3)
+
+
+def test_two_tile_attention_kernel_matches_the_one_tile_form_bf16(dev):
+    """attention2_kernel (two query tiles per wave, keys in halves of 128 with an online softmax) against attention_kernel (all
+    keys at once), FLAIR_SF_ATT2 = 1 / 0, on 16, 64, 144 and 256 reduced keys: same products, different summation order of the
+    softmax denominator and one more rescale — bf16 rounding level."""
+    from flair_amd import _lib as L
+    _, hip = _pair(dev, "bf16")
+    for side in (128, 256, 384, 512):
+        x = torch.randn(1, 5, side, side, generator=torch.Generator().manual_seed(side))
+        a = hip(x.to(dev)).logits.cpu()
+        try:
+            L.check(L.lib().flair_tune_set(b"FLAIR_SF_ATT2", 0))
+            b = hip(x.to(dev)).logits.cpu()
+        finally:
+            L.lib().flair_tune_set(b"FLAIR_SF_ATT2", 1)
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) < 1e-2 * scale and float((a - b).pow(2).mean().sqrt()) < 2e-3 * scale, side
 
 
 def test_contract(dev):
