@@ -63,6 +63,64 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out
   }
 }
 
+// The stem's BatchNorm + ReLU and the 3x3 / stride-2 max pool in one pass over the pre-BN tensor: a thread normalises the nine
+// taps of its window (the rounding sequence of bn_act: fmaf, max, round to T), pools the rounded values exactly like
+// maxpool_fwd_kernel does on the stored activation, and writes the activation of the 2 x 2 pixels it owns (rows 2 ho, 2 ho + 1,
+// columns 2 wo, 2 wo + 1 = taps r, q in {1, 2}).  Saves the pool's re-read of the 268 MB activation.
+template <typename T>
+__global__ void bn_act_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                      T* __restrict__ act, T* __restrict__ out, unsigned char* __restrict__ idx, int N, int H, int W, int C) {
+  constexpr int CH = Elem<T>::CH;
+  const int Ho = H / 2, Wo = W / 2, cpr = C / CH;
+  const int ho = blockIdx.x % Ho, n = blockIdx.x / Ho;
+  const unsigned row_items = (unsigned)Wo * cpr;
+  for (unsigned it = threadIdx.x; it < row_items; it += blockDim.x) {
+    const int cx = (int)(it % (unsigned)cpr), wo = (int)(it / (unsigned)cpr);
+    const long i = ((long)blockIdx.x * Wo + wo) * cpr + cx;
+    float sc[CH], sh[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { sc[e] = scale[cx * CH + e]; sh[e] = shift[cx * CH + e]; }
+    float best[CH];
+    unsigned char bi[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    bool first = true;
+    for (int r = 0; r < 3; ++r) {
+      const int h = 2 * ho - 1 + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int q = 0; q < 3; ++q) {
+        const int w = 2 * wo - 1 + q;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const long off = (((long)n * H + h) * W + w) * C + cx * CH;
+        float f[CH];
+        chunk_to_f<T>(*reinterpret_cast<const uint4*>(y + off), f);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
+        const uint4 a = f_to_chunk<T>(f);
+        if (r >= 1 && q >= 1) *reinterpret_cast<uint4*>(act + off) = a;
+        chunk_to_f<T>(a, f);   // the stored (rounded) activation is what is pooled
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          if (first || f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; bi[e] = (unsigned char)(r * 3 + q); }
+        }
+        first = false;
+      }
+    }
+    *reinterpret_cast<uint4*>(out + i * CH) = f_to_chunk<T>(best);
+    if (idx) {
+      if constexpr (CH == 8) {
+        uint2 iv;
+        iv.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+        iv.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+        *reinterpret_cast<uint2*>(idx + i * CH) = iv;
+      } else {
+        *reinterpret_cast<unsigned*>(idx + i * CH) =
+            (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+      }
+    }
+  }
+}
+
 // bnr_*: optional first pass of the BatchNorm backward of the unit whose ReLU output this gradient belongs to (the stem): the
 // kernel completes that gradient, so it also leaves sum(dz*m), sum(dz*m*y), m = [y*msc + msh > 0], per workgroup in
 // bnr_partial[2][C][gridDim.x] — what bn_bwd_reduce_kernel would re-read the 268 MB tensor for.
@@ -431,6 +489,21 @@ int maxpool3x3s2_fwd(int dtype, const void* in, void* out, unsigned char* idx, i
     hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(N * (H / 2)), dim3(256), 0, s, (const float*)in, (float*)out, idx, N, H, W, C);
   else
     hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(N * (H / 2)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, idx, N, H, W, C);
+  FLAIR_CHECK_LAUNCH();
+  return 0;
+}
+
+int bn_act_maxpool3x3s2(int dtype, const void* y, const float* scale, const float* shift, void* act, void* out, unsigned char* idx, int N, int H,
+                        int W, int C, hipStream_t s) {
+  const int ch = dtype == DT_F32 ? 4 : 8;
+  if (C % ch || (H & 1) || (W & 1) || (256 % (C / ch))) return -2;
+  ProfScope ps("bn_act_maxpool", 0.0, (double)N * H * W * C * dtype_size(dtype) * 2.25 + (double)N * H * W * C / 4, s);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(bn_act_maxpool_kernel<float>, dim3(N * (H / 2)), dim3(256), 0, s, (const float*)y, scale, shift, (float*)act, (float*)out, idx,
+                       N, H, W, C);
+  else
+    hipLaunchKernelGGL(bn_act_maxpool_kernel<bf16_t>, dim3(N * (H / 2)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)act, (bf16_t*)out,
+                       idx, N, H, W, C);
   FLAIR_CHECK_LAUNCH();
   return 0;
 }

@@ -25,6 +25,9 @@ int colsum(int dtype, const void* x, long rows, int ld, int C, float* partial, f
 
 // ---- misc.hip
 int maxpool3x3s2_fwd(int dtype, const void* in, void* out, unsigned char* idx, int N, int H, int W, int C, hipStream_t s);
+// act = relu(y * scale + shift) and its 3x3 / stride-2 max pool (+ tap indices) in one pass (the stem in training mode)
+int bn_act_maxpool3x3s2(int dtype, const void* y, const float* scale, const float* shift, void* act, void* out, unsigned char* idx, int N, int H,
+                        int W, int C, hipStream_t s);
 int maxpool3x3s2_bwd(int dtype, const void* dout, const unsigned char* idx, void* din, int accumulate, int N, int H,
                      int W, int C, hipStream_t s, const void* bnr_y = nullptr, const float* bnr_msc = nullptr,
                      const float* bnr_msh = nullptr, float* bnr_partial = nullptr);   // bnr_*: fused BN-backward reduction, [2][C][N*H] partials

@@ -400,11 +400,17 @@ void UNet::encoder_fwd_impl(const float* x_nchw) {
   RUN(nchw_f32_to_nhwc(dtype, x_nchw, xin_.p, B_, in_channels, H_, W_, xin_.C, s_));
   Act none;
   int ci = 0, bi = 0;
-  int u = run_unit(ci++, bi++, xin_, none, false, true, -1, none, true);
+  // training: the stem's BatchNorm + ReLU pass and the max pool read the pre-BN tensor together (bn_act_maxpool_kernel)
+  const bool fuse_pool = training_ && tune("FLAIR_STEM_POOL", 1);
+  int u = run_unit(ci++, bi++, xin_, none, false, true, -1, none, !fuse_pool);
+  if (fuse_pool) units_[u].out = alloc_act(units_[u].y.N, units_[u].y.H, units_[u].y.W, units_[u].y.C);
   f_[1] = units_[u].out;
   pool_ = alloc_act(B_, f_[1].H / 2, f_[1].W / 2, 64);
   pool_idx_ = training_ ? (unsigned char*)alloc((size_t)pool_.elems()) : nullptr;
-  RUN(maxpool3x3s2_fwd(dtype, f_[1].p, pool_.p, pool_idx_, B_, f_[1].H, f_[1].W, 64, s_));
+  if (fuse_pool)
+    RUN(bn_act_maxpool3x3s2(dtype, units_[u].y.p, units_[u].scale, units_[u].shift, f_[1].p, pool_.p, pool_idx_, B_, f_[1].H, f_[1].W, 64, s_));
+  else
+    RUN(maxpool3x3s2_fwd(dtype, f_[1].p, pool_.p, pool_idx_, B_, f_[1].H, f_[1].W, 64, s_));
   Act x = pool_;
   const int nblk[4] = {3, 4, 6, 3};
   for (int L = 0; L < 4; ++L) {
