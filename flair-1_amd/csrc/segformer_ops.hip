@@ -570,16 +570,23 @@ __global__ __launch_bounds__(256) void ffn_dw_pack_kernel(const float* __restric
   out[i] = tp < 9 ? w[ch * 9 + tp] : b[ch];
 }
 
+// 512 threads: a tile's serial chain (halo load, LayerNorm, then per chunk fc1 -> barrier -> depth-wise -> barrier -> fc2) is what
+// bounds the kernel at two workgroups per CU, so eight waves split every phase: fc1 by halo pixel tile (7 of the 8 waves), the
+// depth-wise phase two pixels per thread, fc2 by (pixel tile, K half) with the halves added through LDS once per tile.
+// (Four waves per tile: 261 us per stage-0 block.)
+constexpr int FFN_NT = 512;
+
 template <int C>
-__global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                                        const bf16_t* __restrict__ w1 /* [4C][C] */, const float* __restrict__ b1,
-                                                        const float* __restrict__ dwp /* [C][10][4] */, const bf16_t* __restrict__ w2 /* [C][4C] */,
-                                                        const float* __restrict__ b2, bf16_t* __restrict__ out, int B, int H, int W, float eps,
-                                                        const float* __restrict__ ln2_g, const float* __restrict__ ln2_b,
-                                                        bf16_t* __restrict__ out_ln /* optional: LayerNorm(out) with ln2_*, the next consumer's input */) {
+__global__ __launch_bounds__(FFN_NT) __attribute__((amdgpu_waves_per_eu(C == 64 ? 4 : 2, 8))) void ffn_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                           const bf16_t* __restrict__ w1 /* [4C][C] */, const float* __restrict__ b1,
+                                                           const float* __restrict__ dwp /* [C][10][4] */, const bf16_t* __restrict__ w2 /* [C][4C] */,
+                                                           const float* __restrict__ b2, bf16_t* __restrict__ out, int B, int H, int W, float eps,
+                                                           const float* __restrict__ ln2_g, const float* __restrict__ ln2_b,
+                                                           bf16_t* __restrict__ out_ln /* optional: LayerNorm(out) with ln2_*, the next consumer's input */) {
   using Cfg = FfnCfg<C>;
+  constexpr int NT = FFN_NT;
   constexpr int XROW = Cfg::XROW, ROW = Cfg::ROW, CPR = C / 8, KS1 = C / 32, MT2 = C / 16, NCHUNK = 4 * C / 64, HID = 4 * C;
-  constexpr int NW = C / 32;   // 16-byte items per thread of a W1 / W2 chunk (64 rows x C, C rows x 64)
+  constexpr int NW = (64 * CPR + NT - 1) / NT;   // 16-byte items per thread of a W1 / W2 chunk (64 rows x C, C rows x 64)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xs = smem;
   unsigned char* h1 = smem + Cfg::OFF_H1;
@@ -593,12 +600,12 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict
   const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
   const int x0 = tx * 8, y0 = ty * 8;
   const bf16_t* xb = x + (long)b * H * W * C;
-  // ---- weight staging: registers of this thread for the next chunk
+  // ---- weight staging: registers of this thread for the next chunk (64 * CPR = 512 or 1024 items of 16 bytes per matrix)
   u32x4 rw1[NW], rw2[NW], rdw = u32x4{0u, 0u, 0u, 0u};
   auto ld_w1 = [&](int hc) {   // + the chunk's fc1 bias (threads 160 .. 175) and depth-wise taps (threads < 160) ride along
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
-      const int i = t + 256 * k, row = i / CPR, part = i - row * CPR;
+      const int i = t + NT * k, row = i / CPR, part = i - row * CPR;
       rw1[k] = *reinterpret_cast<const u32x4*>(w1 + (long)(hc * 64 + row) * C + part * 8);
     }
     if (t < 160) rdw = *reinterpret_cast<const u32x4*>(dwp + ((long)hc * 160 + t) * 4);
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict
   auto st_w1 = [&]() {         // W1 rows + bias (read by fc1)
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
-      const int i = t + 256 * k, row = i / CPR, part = i - row * CPR;
+      const int i = t + NT * k, row = i / CPR, part = i - row * CPR;
       *reinterpret_cast<u32x4*>(w1s + row * XROW + part * 16) = rw1[k];
     }
     if (t >= 160 && t < 176) *reinterpret_cast<u32x4*>(b1s + (t - 160) * 16) = rdw;
@@ -618,14 +625,14 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict
   auto ld_w2 = [&](int hc) {
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
-      const int i = t + 256 * k, row = i >> 3, part = i & 7;
+      const int i = t + NT * k, row = i >> 3, part = i & 7;
       rw2[k] = *reinterpret_cast<const u32x4*>(w2 + (long)row * HID + hc * 64 + part * 8);
     }
   };
   auto st_w2 = [&]() {
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
-      const int i = t + 256 * k, row = i >> 3, part = i & 7;
+      const int i = t + NT * k, row = i >> 3, part = i & 7;
       *reinterpret_cast<u32x4*>(w2s + row * ROW + part * 16) = rw2[k];
     }
   };
@@ -634,11 +641,11 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict
   // ---- X halo tile -> LDS (zeros outside the image; rows 100 .. 111 are never consumed but must be finite); all loads of a
   // thread are issued before the first LDS write
   {
-    constexpr int NIT = (Cfg::HROWS * CPR + 255) / 256;
+    constexpr int NIT = (Cfg::HROWS * CPR + NT - 1) / NT;
     u32x4 v[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int i = t + 256 * k, hp = i / CPR, part = i - hp * CPR;
+      const int i = t + NT * k, hp = i / CPR, part = i - hp * CPR;
       const int hy = hp / 10, hx = hp - hy * 10;
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
       const bool ok = hp < Cfg::HPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
@@ -647,20 +654,20 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int i = t + 256 * k, hp = i / CPR, part = i - hp * CPR;
+      const int i = t + NT * k, hp = i / CPR, part = i - hp * CPR;
       if (i < Cfg::HROWS * CPR) *reinterpret_cast<u32x4*>(xs + hp * XROW + part * 16) = v[k];
     }
   }
   st_w1();
   st_dw();
   __syncthreads();
-  // ---- LayerNorm in place, TWO threads per halo pixel, each half of the channels (mean, biased variance of the centred values,
-  // eps inside the root); the halves meet through a lane shuffle
+  // ---- LayerNorm in place, FOUR threads per halo pixel, each a quarter of the channels (mean, biased variance of the centred
+  // values, eps inside the root); the quarters meet through lane shuffles
   {
-    const int hp = t >> 1, half = t & 1;
+    const int hp = t >> 2, qtr = t & 3;
     const bool live = hp < Cfg::HPX;
-    unsigned char* row = xs + (live ? hp : 0) * XROW + half * (C / 2) * 2;
-    constexpr int HC = CPR / 2;   // 16-byte chunks per half row
+    unsigned char* row = xs + (live ? hp : 0) * XROW + qtr * (C / 4) * 2;
+    constexpr int HC = CPR / 4;   // 16-byte chunks per quarter row
     float f[HC][8];
     float sum = 0.f;
 #pragma unroll
@@ -670,6 +677,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict
       for (int e = 0; e < 8; ++e) sum += f[c][e];
     }
     sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
     const float mean = sum / (float)C;
     float q = 0.f;
 #pragma unroll
@@ -677,27 +685,28 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float d = f[c][e] - mean; q = fmaf(d, d, q); }
     q += __shfl_xor(q, 1);
+    q += __shfl_xor(q, 2);
     const float rstd = 1.f / sqrtf(q / (float)C + eps);
     if (live) {
 #pragma unroll
       for (int c = 0; c < HC; ++c) {
-        const int c0 = half * (C / 2) + c * 8;
+        const int c0 = qtr * (C / 4) + c * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[c][e] = fmaf((f[c][e] - mean) * rstd, ln_g[c0 + e], ln_b[c0 + e]);
         *reinterpret_cast<uint4*>(row + c * 16) = f_to_chunk<bf16_t>(f[c]);
       }
     }
   }
-  // ---- per-lane constants: which of this wave's fc1 pixel tiles (wave, wave + 4) hold in-image pixels
-  bool inimg[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int hp = (wave + 4 * k) * 16 + lr, hy = hp / 10, hx = hp - hy * 10;
-    inimg[k] = hp < Cfg::HPX && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+  // ---- per-lane constant: does this wave's fc1 pixel tile (halo rows 16 wave .. + 15, waves 0 .. 6) hold an in-image pixel here
+  bool inimg;
+  {
+    const int hp = wave * 16 + lr, hy = hp / 10, hx = hp - hy * 10;
+    inimg = hp < Cfg::HPX && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
   }
-  const int npt = wave < 3 ? 2 : 1;                  // 7 pixel tiles of 16 halo rows over 4 waves
-  // depth-wise item of this thread: channel group gq (4 channels), row py, half xh (4 pixels)
-  const int gq = t & 15, seg = t >> 4, py = seg >> 1, xh = seg & 1;
+  // depth-wise item of this thread: channel group gq (4 channels), row py, quarter xq (2 pixels)
+  const int gq = t & 15, seg = t >> 4, py = seg >> 2, xq = seg & 3;
+  // fc2 item of this wave: pixel tile pt2 (16 pixels), K half kh of the chunk's 64 hidden channels
+  const int pt2 = wave & 3, kh = wave >> 2;
   f32x4_t acc2[MT2];
 #pragma unroll
   for (int m = 0; m < MT2; ++m) acc2[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -705,104 +714,108 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const bf16_t* __restrict
   for (int hc = 0; hc < NCHUNK; ++hc) {
     // rw2 holds W2's chunk hc (loaded a chunk ago); the next chunk's W1 / bias / taps start their trip now
     if (hc + 1 < NCHUNK) ld_w1(hc + 1);
-    // ---- fc1 on the halo: H1[ch][px], this wave's pixel tiles x the chunk's four 16-channel tiles
+    // ---- fc1 on the halo: H1[ch][px], this wave's pixel tile x the chunk's four 16-channel tiles
+    if (wave < 7) {   // wave-uniform
+      const int pt = wave;
+      u32x4 bx[KS1];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (k < npt) {   // wave-uniform
-        const int pt = wave + 4 * k;
-        u32x4 bx[KS1];
+      for (int ks = 0; ks < KS1; ++ks) bx[ks] = *reinterpret_cast<const u32x4*>(xs + (pt * 16 + lr) * XROW + (ks * 32 + 8 * g) * 2);
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) bx[ks] = *reinterpret_cast<const u32x4*>(xs + (pt * 16 + lr) * XROW + (ks * 32 + 8 * g) * 2);
+      for (int ct = 0; ct < 4; ++ct) {
+        f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < KS1; ++ks) {
-            const u32x4 wf = *reinterpret_cast<const u32x4*>(w1s + (ct * 16 + lr) * XROW + (ks * 32 + 8 * g) * 2);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, bx[ks]), a, 0, 0, 0);
-          }
-          const float4 bb = *reinterpret_cast<const float4*>(b1s + (ct * 16 + 4 * g) * 4);
-          const float v0 = inimg[k] ? a[0] + bb.x : 0.f, v1 = inimg[k] ? a[1] + bb.y : 0.f;
-          const float v2 = inimg[k] ? a[2] + bb.z : 0.f, v3 = inimg[k] ? a[3] + bb.w : 0.f;
-          uint2 pk;
-          pk.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
-          pk.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
-          *reinterpret_cast<uint2*>(h1 + (pt * 16 + lr) * ROW + (ct * 16 + 4 * g) * 2) = pk;
+        for (int ks = 0; ks < KS1; ++ks) {
+          const u32x4 wf = *reinterpret_cast<const u32x4*>(w1s + (ct * 16 + lr) * XROW + (ks * 32 + 8 * g) * 2);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, bx[ks]), a, 0, 0, 0);
         }
+        const float4 bb = *reinterpret_cast<const float4*>(b1s + (ct * 16 + 4 * g) * 4);
+        const float v0 = inimg ? a[0] + bb.x : 0.f, v1 = inimg ? a[1] + bb.y : 0.f;
+        const float v2 = inimg ? a[2] + bb.z : 0.f, v3 = inimg ? a[3] + bb.w : 0.f;
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+        pk.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+        *reinterpret_cast<uint2*>(h1 + (pt * 16 + lr) * ROW + (ct * 16 + 4 * g) * 2) = pk;
       }
     }
     __syncthreads();                                 // H1 complete; every wave is past fc1 (W1 / bias image free), fc2 of hc - 1 (W2 free)
     st_w2();                                         // W2 chunk hc for this chunk's fc2
     if (hc + 1 < NCHUNK) ld_w2(hc + 1);
-    // ---- depth-wise 3 x 3 + GELU: four outputs along x from a sliding 3 x 6 window of H1 (halo rows py .. py + 2)
+    // ---- depth-wise 3 x 3 + GELU: two outputs along x from a 3 x 4 window of H1 (halo rows py .. py + 2)
     {
       float4 dw[10];
 #pragma unroll
       for (int k = 0; k < 10; ++k) dw[k] = *reinterpret_cast<const float4*>(dws + (gq * 10 + k) * 16);
-      float win[3][3][4];
-      auto rd = [&](int slot, int col) {
+      float o[2][4];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const uint2 v = *reinterpret_cast<const uint2*>(h1 + ((py + r) * 10 + xh * 4 + col) * ROW + gq * 8);
-          win[slot][r][0] = __uint_as_float(v.x << 16); win[slot][r][1] = __uint_as_float(v.x & 0xffff0000u);
-          win[slot][r][2] = __uint_as_float(v.y << 16); win[slot][r][3] = __uint_as_float(v.y & 0xffff0000u);
+      for (int i = 0; i < 2; ++i) { o[i][0] = dw[9].x; o[i][1] = dw[9].y; o[i][2] = dw[9].z; o[i][3] = dw[9].w; }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {   // one window row at a time (the whole 3 x 4 window in registers spills at four waves per SIMD);
+                                      // per output the taps still accumulate row-major: r, then q
+        float win[4][4];
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+          const uint2 v = *reinterpret_cast<const uint2*>(h1 + ((py + r) * 10 + xq * 2 + col) * ROW + gq * 8);
+          win[col][0] = __uint_as_float(v.x << 16); win[col][1] = __uint_as_float(v.x & 0xffff0000u);
+          win[col][2] = __uint_as_float(v.y << 16); win[col][3] = __uint_as_float(v.y & 0xffff0000u);
         }
-      };
-      rd(0, 0);
-      rd(1, 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rd((i + 2) % 3, i + 2);
-        float o[4] = {dw[9].x, dw[9].y, dw[9].z, dw[9].w};
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int qq = 0; qq < 3; ++qq) {
             const float4 wv = dw[r * 3 + qq];
-            const float* xv = win[(i + qq) % 3][r];
-            o[0] = fmaf(xv[0], wv.x, o[0]); o[1] = fmaf(xv[1], wv.y, o[1]); o[2] = fmaf(xv[2], wv.z, o[2]); o[3] = fmaf(xv[3], wv.w, o[3]);
+            const float* xv = win[i + qq];
+            o[i][0] = fmaf(xv[0], wv.x, o[i][0]); o[i][1] = fmaf(xv[1], wv.y, o[i][1]);
+            o[i][2] = fmaf(xv[2], wv.z, o[i][2]); o[i][3] = fmaf(xv[3], wv.w, o[i][3]);
           }
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = gelu_erf<bf16_t>(o[e]);
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[i][e] = gelu_erf<bf16_t>(o[i][e]);
         uint2 pk;
-        pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-        pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
-        *reinterpret_cast<uint2*>(a2 + (py * 8 + xh * 4 + i) * ROW + gq * 8) = pk;
+        pk.x = (unsigned)f32_to_bf16(o[i][0]) | ((unsigned)f32_to_bf16(o[i][1]) << 16);
+        pk.y = (unsigned)f32_to_bf16(o[i][2]) | ((unsigned)f32_to_bf16(o[i][3]) << 16);
+        *reinterpret_cast<uint2*>(a2 + (py * 8 + xq * 2 + i) * ROW + gq * 8) = pk;
       }
     }
     if (hc + 1 < NCHUNK) st_w1();                    // next chunk's W1 rows + bias (their readers start behind the barrier below)
     __syncthreads();                                 // A2 and W2 complete; every wave is past the depth-wise phase (tap image free)
     if (hc + 1 < NCHUNK) st_dw();
-    // ---- fc2: OUT[c][px] += W2[:, chunk] A2^T, this wave's 16 pixels
+    // ---- fc2: OUT[c][px] += W2[:, chunk K half] A2^T, this wave's 16 pixels and 32 of the chunk's hidden channels
     {
-      u32x4 ba[2];
+      const u32x4 ba = *reinterpret_cast<const u32x4*>(a2 + (pt2 * 16 + lr) * ROW + (kh * 32 + 8 * g) * 2);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) ba[ks] = *reinterpret_cast<const u32x4*>(a2 + (wave * 16 + lr) * ROW + (ks * 32 + 8 * g) * 2);
-#pragma unroll
-      for (int m = 0; m < MT2; ++m)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const u32x4 wf = *reinterpret_cast<const u32x4*>(w2s + (m * 16 + lr) * ROW + (ks * 32 + 8 * g) * 2);
-          acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, ba[ks]), acc2[m], 0, 0, 0);
-        }
+      for (int m = 0; m < MT2; ++m) {
+        const u32x4 wf = *reinterpret_cast<const u32x4*>(w2s + (m * 16 + lr) * ROW + (kh * 32 + 8 * g) * 2);
+        acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, ba), acc2[m], 0, 0, 0);
+      }
     }
     // (no barrier here: the next writers of H1 / A2 / W2 sit behind the next chunk's first barrier)
   }
-  // ---- x_out = OUT + b2 + x: lane holds channels 16 m + 4 g .. + 3 of pixel (wave * 16 + lr)
-  {
-    const int p = wave * 16 + lr, gy = y0 + (p >> 3), gx = x0 + (p & 7);
+  // ---- the two K halves of a pixel tile meet: waves 4 .. 7 hand their sums to waves 0 .. 3 through LDS (the X image is free)
+  __syncthreads();
+  float* xch = reinterpret_cast<float*>(smem);   // [4 pixel tiles][MT2][64 lanes] float4
+  if (kh == 1) {
+#pragma unroll
+    for (int m = 0; m < MT2; ++m) *reinterpret_cast<f32x4_t*>(xch + ((pt2 * MT2 + m) * 64 + lane) * 4) = acc2[m];
+  }
+  __syncthreads();
+  // ---- x_out = OUT + b2 + x: lane holds channels 16 m + 4 g .. + 3 of pixel (pt2 * 16 + lr)
+  if (kh == 0) {   // wave-uniform
+    const int p = pt2 * 16 + lr, gy = y0 + (p >> 3), gx = x0 + (p & 7);
     const long base = (((long)b * H + gy) * W + gx) * C;
     float xo[MT2][4];
 #pragma unroll
     for (int m = 0; m < MT2; ++m) {
+      const f32x4_t other = *reinterpret_cast<const f32x4_t*>(xch + ((pt2 * MT2 + m) * 64 + lane) * 4);
       const int c = m * 16 + 4 * g;
       const uint2 rv = *reinterpret_cast<const uint2*>(x + base + c);
       const float4 bb = *reinterpret_cast<const float4*>(b2 + c);
       const float r0 = __uint_as_float(rv.x << 16), r1 = __uint_as_float(rv.x & 0xffff0000u);
       const float r2 = __uint_as_float(rv.y << 16), r3 = __uint_as_float(rv.y & 0xffff0000u);
       uint2 pk;
-      pk.x = (unsigned)f32_to_bf16(acc2[m][0] + bb.x + r0) | ((unsigned)f32_to_bf16(acc2[m][1] + bb.y + r1) << 16);
-      pk.y = (unsigned)f32_to_bf16(acc2[m][2] + bb.z + r2) | ((unsigned)f32_to_bf16(acc2[m][3] + bb.w + r3) << 16);
+      pk.x = (unsigned)f32_to_bf16(acc2[m][0] + other[0] + bb.x + r0) | ((unsigned)f32_to_bf16(acc2[m][1] + other[1] + bb.y + r1) << 16);
+      pk.y = (unsigned)f32_to_bf16(acc2[m][2] + other[2] + bb.z + r2) | ((unsigned)f32_to_bf16(acc2[m][3] + other[3] + bb.w + r3) << 16);
       *reinterpret_cast<uint2*>(out + base + c) = pk;
       // the stored (rounded) values: what a separate LayerNorm pass would read back
       xo[m][0] = __uint_as_float(pk.x << 16); xo[m][1] = __uint_as_float(pk.x & 0xffff0000u);
@@ -1361,7 +1374,7 @@ static int ffn_fused_launch(const void* x, const float* ln_g, const float* ln_b,
   }
   const long tiles = (long)B * (H / 8) * (W / 8);
   if (tiles > (1L << 30)) return -2;
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), FfnCfg<C>::SMEM, s, (const bf16_t*)x, ln_g, ln_b, (const bf16_t*)w1, b1, dwp,
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(FFN_NT), FfnCfg<C>::SMEM, s, (const bf16_t*)x, ln_g, ln_b, (const bf16_t*)w1, b1, dwp,
                      (const bf16_t*)w2, b2, (bf16_t*)out, B, H, W, eps, ln2_g, ln2_b, (bf16_t*)out_ln);
   FLAIR_CHECK_LAUNCH();
   return 0;
