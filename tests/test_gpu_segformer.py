@@ -131,6 +131,20 @@ def test_fused_mix_ffn_kernel_matches_the_separate_passes_bf16(dev, shape):
     assert float((fused - want).abs().max()) < 3e-2 * scale and float((fused - want).pow(2).mean().sqrt()) < 6e-3 * scale
 
 
+def test_bf16_shapes_the_fused_kernels_do_not_take(dev):
+    """512 x 96 (16 x 3 = 48 reduced keys) is a valid tile whose 1/4 grid is 24 wide — not a whole number of the fused decode
+    head's 16-pixel tiles — and whose stage-1 grid is 12 wide — not a whole number of the fused Mix-FFN's 8 x 8 tiles: those two
+    fall back to the separate passes (stage 0 stays fused), batch 3.  Same bf16 rule as below."""
+    from oracle import parity
+    from oracle import segformer as osf
+    ref, hip = _pair(dev, "bf16")
+    x = torch.randn(3, 5, 512, 96, generator=torch.Generator().manual_seed(5))
+    _, lf = osf.logits(ref, x)
+    gf = hip.forward_full(x.to(dev)).cpu()
+    parity.assert_masks_within_logit_error("segformer_b2_bf16_3x512x96", lf.numpy(), gf.numpy(), gf.argmax(1).numpy(),
+                                           max_rel_dlogit=3e-2, max_rel_rms=6e-3)
+
+
 @pytest.mark.parametrize("side", [512, 384])
 def test_bf16_mode_tracks_the_oracle(dev, side):
     """bf16 throughput mode: the logit-error rule of oracle/parity.py (measured: max |dlogit| 1.0e-2 and rms 1.9e-3 of the
