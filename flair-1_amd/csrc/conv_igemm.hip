@@ -395,8 +395,13 @@ static int launch_t(const ConvArgs& a, hipStream_t s) {
   const long M = (long)a.N * a.Hout * a.Wout;
   const int bn = pick_bn(a.Cout);
   const bool small = !a.stats && !a.ncls && bn >= 64 && a.Kpad >= 8 * 8 * Elem<T>::CH && (long)cdiv(M, 128) * cdiv(a.Cout, bn) < 256 &&
-                     tune("FLAIR_IGEMM_BM32", 1);
-  if (small) return bn == 128 ? launch_cfg<T, 32, 128, 2, 2>(a, s) : launch_cfg<T, 32, 64, 2, 2>(a, s);
+                     tune("FLAIR_IGEMM_BM32", 2);
+  if (small) {
+    // (32 x 32 tiles when even the 32-row tiles leave CUs without a second workgroup: K = 4 096 at 64 output channels)
+    const int mode = tune("FLAIR_IGEMM_BM32", 2);
+    if (mode >= 2 && (long)cdiv(M, 32) * cdiv(a.Cout, bn) < 512) return launch_cfg<T, 32, 32, 2, 2>(a, s);
+    return bn == 128 ? launch_cfg<T, 32, 128, 2, 2>(a, s) : launch_cfg<T, 32, 64, 2, 2>(a, s);
+  }
   switch (bn) {
     case 128: return launch_cfg<T, 128, 128, 2, 2>(a, s);
     case 64: return launch_cfg<T, 128, 64, 4, 1>(a, s);
